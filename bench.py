@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s (+ Mrays/s) of the hip render module on the Stanford-dragon scene at
+1920x1080 (BASELINE.json config 4), with inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 8 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (trh_render) over the whole frame for --spp-per-step new
+samples per pixel on every rank (weak scaling: disjoint global sample-index blocks per rank).
+The timed region holds exactly K steps on every rank plus the path's one exchange step (sum-
+reduce of the float4 accumulation buffer to rank 0 over RCCL) and the device-side resolve;
+no PCIe transfer is inside it. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(st):
+    """F_ray = 25*n_box + 59*n_tri + 180*[hit] + 12*n_tex + 25*[miss] + 8*[RR],
+    + 58 per sample (camera ray 50 + accumulate 8). n_box / n_tri / hits / tex are COUNTED by the
+    instrumented kernel on this very workload (trh_render_stats), not assumed."""
+    miss = st["rays"] - st["hits"]
+    return (25.0 * st["box_tests"] + 59.0 * st["tri_tests"] + 180.0 * st["hits"] + 12.0 * st["tex_fetches"]
+            + 25.0 * miss + 8.0 * st["hits"] + 58.0 * st["samples"])
+
+
+def algorithmic_bytes(st):
+    """Secondary figure: 64 B per inner-node record visit (2 boxes), 48 B per triangle test,
+    172 B per hit (64 B shading record + hit bookkeeping), 16 B per texel, 32 B per sample."""
+    return (32.0 * st["box_tests"] + 48.0 * st["tri_tests"] + 172.0 * st["hits"] + 16.0 * st["tex_fetches"] + 32.0 * st["samples"])
+
+
+def cpu_baseline(scene_name, width, height, budget_s=12.0):
+    """The CPU oracle (oracle/cpu_ref.cpp, a restatement of the reference's OpenMP module) timed on
+    this host's cores on a bounded sample of the same workload: whole frames (1 spp each) of the
+    same scene at the same resolution until ~budget_s of wall time is used."""
+    from tracy_amd.scene import Scene
+    from oracle.oracle import CpuRef, lib
+    sc = Scene(f"data/scenes/{scene_name}.scn", width, height)
+    ref = CpuRef(sc)
+    threads = lib().oref_num_threads()
+    t0 = time.time()
+    ref.render(0, 1)
+    first = time.time() - t0
+    n = int(max(1, min(32, budget_s / max(first, 1e-3))))
+    ref.counters(reset=True)
+    t0 = time.time()
+    ref.render(1, n)
+    dt = time.time() - t0
+    rays = ref.counters()["rays"]
+    return {"value": width * height * n / dt / 1e6, "unit": "Msamples/s", "mrays_per_s": rays / dt / 1e6, "cores": threads,
+            "kind": "port", "sample": f"{scene_name} {width}x{height}, {n} spp (whole frames), reference kd-tree, OpenMP {threads} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--scene", default="dragon")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--pipeline", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save", default=None, help="rank 0: write the resolved image as .npy")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tracy_amd import Scene, HipTrace
+    from tracy_amd import sharding
+
+    rank, world, local_rank = sharding.env_rank_world()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene = Scene(f"data/scenes/{args.scene}.scn", args.width, args.height)
+    mod = HipTrace(device=local_rank, pipeline=args.pipeline)
+    mod.Startup(scene)
+    W, H, S = scene.width, scene.height, args.spp_per_step
+
+    # accumulation buffer owned by torch so that torch.distributed (RCCL) can reduce it in place
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    mod.bind_accum_buffer(accum.data_ptr(), accum.numel() * 4)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- instrumented pass (untimed): the roofline numerator for one launch of this workload
+    mod.stats(reset=True)
+    mod.render(*sharding.step_sample_range(rank, world, 0, S), stats=True)
+    st_algo = mod.stats(reset=True)
+    accum.zero_()
+
+    # ---- warmup
+    step = 0
+    for _ in range(args.warmup):
+        mod.render(*sharding.step_sample_range(rank, world, step, S))
+        step += 1
+    mod.synchronize()
+    if world > 1:
+        sharding.reduce_accum_to_root(accum.clone(), dist)   # RCCL warm-up on a scratch copy
+    accum.zero_()
+    mod.stats(reset=True)
+    first_timed = step
+
+    # ---- timed region: exactly K steps + the exchange step + device-side resolve
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mod.render(*sharding.step_sample_range(rank, world, step, S))
+        step += 1
+    mod.synchronize()
+    sharding.reduce_accum_to_root(accum, dist if world > 1 else None)
+    if world > 1:
+        torch.cuda.synchronize()     # the reduce runs on torch's RCCL stream, the resolve on the module's
+    if rank == 0:
+        mod.resolve(to_host=False)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    st = mod.stats(reset=False)
+    t_all = torch.tensor([dt, float(st["rays"]), float(st["samples"])], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        tmax = t_all.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t_all.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        total_rays, total_samples = float(tsum[1]), float(tsum[2])
+    else:
+        total_rays, total_samples = float(st["rays"]), float(st["samples"])
+
+    if rank == 0:
+        # PCIe-inclusive figure, reported separately (never `value`)
+        t1 = time.perf_counter()
+        img, _ = mod.resolve(to_host=True)
+        d2h_ms = (time.perf_counter() - t1) * 1e3
+        if args.save:
+            np.save(args.save, img)
+        kernel_ms = st["kernel_ms"] / max(1, st["launches"])
+        flops_launch = algorithmic_flops(st_algo)
+        bytes_launch = algorithmic_bytes(st_algo)
+        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"{args.scene}_{W}x{H}_{S}spp")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/s @1080p dragon scene (path tracing, <=5 bounces, Russian roulette)",
+            "value": total_samples / dt / 1e6,
+            "unit": "Msamples/s",
+            "mrays_per_s": total_rays / dt / 1e6,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene}.scn {W}x{H}, {S} spp per step per GPU, {scene.tri_count} triangles, "
+                                   f"max 5 bounces + Russian roulette, seed 0xABCDEF (BASELINE.json configs[3])",
+                       "spp_per_step": S, "total_spp": S * args.steps * world, "first_sample_index": first_timed * world * S,
+                       "parallelism": f"sample-index sharding x{world}, one sum-reduce to rank 0",
+                       "pipeline": "megakernel" if not args.pipeline else "wavefront",
+                       "bvh": mod.bvh_info(), "rays_per_sample": total_rays / total_samples},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "kernel": "k_megakernel<false>" if not args.pipeline else "wavefront", "kernel_ms_avg": kernel_ms,
+                         "flops_per_launch": flops_launch,
+                         "per_ray": {"box_tests": st_algo["box_tests"] / st_algo["rays"], "tri_tests": st_algo["tri_tests"] / st_algo["rays"],
+                                     "hit_frac": st_algo["hits"] / st_algo["rays"], "tex_fetches": st_algo["tex_fetches"] / st_algo["rays"]},
+                         "hbm_secondary": {"algorithmic_bytes_per_launch": bytes_launch,
+                                           "achieved_GBs": bytes_launch / (kernel_ms * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS}},
+            "d2h_resolve_ms": d2h_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.scene, W, H)
+        print(json.dumps(out), flush=True)
+
+    mod.bind_accum_buffer(None, 0)
+    mod.Shutdown()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

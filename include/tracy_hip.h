@@ -1,0 +1,204 @@
+/*
+ * tracy_hip.h -- C ABI of the MI355X (gfx950) render module for Tracy ("-kernel hip").
+ *
+ * This is the drop-in boundary of the per-sample path-tracing hot path. A host-side
+ * `HipTrace : TracyModule` (reference interface: src/module.h:17-54) flattens the
+ * reference `Scene` into the POD arrays below and drives the GPU through these entry
+ * points; see INTEGRATION.md for the binding a Tracy maintainer would add.
+ *
+ * Conventions: plain C, plain pointers and sizes, no C++/torch types. Every function
+ * returns 0 on success and a non-zero trh_status on error; trh_last_error() returns a
+ * thread-local message. Input buffers are copied during the call (caller keeps ownership).
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with
+ * TRH_ERR_NO_DEVICE.
+ *
+ * Citations are into the reference tree (carcass82/tracy).
+ */
+#ifndef TRACY_HIP_H
+#define TRACY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRH_ABI_VERSION 1
+
+typedef enum trh_status {
+    TRH_OK = 0,
+    TRH_ERR_INVALID_ARG = 1,
+    TRH_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime error at init */
+    TRH_ERR_HIP = 3,         /* a HIP runtime call failed */
+    TRH_ERR_STATE = 4,       /* call order violated (e.g. render before scene upload) */
+    TRH_ERR_LIMIT = 5        /* size beyond a documented limit */
+} trh_status;
+
+#define TRH_NO_TEXTURE 0xffffffffu
+
+/* Texture slots, same order as Material::TextureID (src/material.h:17). */
+enum { TRH_TEX_BASECOLOR = 0, TRH_TEX_NORMAL = 1, TRH_TEX_ROUGHNESS = 2, TRH_TEX_METALNESS = 3, TRH_TEX_EMISSIVE = 4, TRH_TEX_COUNT = 5 };
+
+/* POD mirror of Material's data members (src/material.h:103-117).
+ * tex[i] == TRH_NO_TEXTURE  <=>  texture_flag_[i] == false. */
+typedef struct trh_material {
+    float albedo[3];
+    float roughness;
+    float metalness;
+    float ior;
+    float emissive[3];     /* already emissive_scale * albedo (src/material.h:24) */
+    float translucent;
+    uint32_t tex[TRH_TEX_COUNT];
+} trh_material;
+
+/* RGBA32F texel array exactly as Texture::pixels_ (src/texture.h:90,93-108):
+ * row 0 first, already divided by 255 and sRGB->linear converted when requested. */
+typedef struct trh_texture {
+    uint32_t width;
+    uint32_t height;
+    const float* rgba;     /* width*height*4 floats */
+} trh_texture;
+
+/* One Mesh (src/mesh.h:106-112). Indices are mesh-local (0..vertex_count-1). */
+typedef struct trh_mesh {
+    uint32_t first_vertex;
+    uint32_t vertex_count;
+    uint32_t first_index;
+    uint32_t index_count;  /* 3 * triangle count */
+    uint32_t material;
+    float aabb_min[3];
+    float aabb_max[3];
+} trh_mesh;
+
+/* Vertex AoS of the reference (src/vertex.h:36-40): 14 floats =
+ * pos[3] normal[3] uv0[2] tangent[3] bitangent[3]. */
+#define TRH_VERTEX_FLOATS 14
+
+#define TRH_FLAG_RUSSIAN_ROULETTE 1u   /* USE_RUSSIAN_ROULETTE (CMakeLists.txt:113)  */
+#define TRH_FLAG_DEFAULT (TRH_FLAG_RUSSIAN_ROULETTE)
+
+typedef struct trh_scene_desc {
+    const float* vertices;       /* vertex_count * TRH_VERTEX_FLOATS */
+    uint32_t vertex_count;
+    const uint32_t* indices;     /* index_count, mesh-local */
+    uint32_t index_count;
+    const trh_mesh* meshes;
+    uint32_t mesh_count;         /* <= 256: mesh id is 8 bit in the packed hit id (cpu_details.h:34) */
+    const trh_material* materials;  /* materials[0] is the sky (src/scene.h:21) */
+    uint32_t material_count;
+    const trh_texture* textures;
+    uint32_t texture_count;
+    uint32_t width;
+    uint32_t height;
+    uint32_t max_bounces;        /* TRACY_MAX_BOUNCES, default 5 (CMakeLists.txt:110) */
+    uint32_t flags;              /* TRH_FLAG_* */
+} trh_scene_desc;
+
+/* Which kernel pipeline trh_render uses. Both produce the same per-sample paths. */
+typedef enum trh_pipeline {
+    TRH_PIPELINE_MEGAKERNEL = 0, /* one persistent kernel, lanes regenerate samples in place */
+    TRH_PIPELINE_WAVEFRONT = 1   /* generate / extend / shade queues, wave64 ballot compaction */
+} trh_pipeline;
+
+typedef struct trh_context trh_context;   /* opaque; one per HIP device */
+
+typedef struct trh_stats {
+    uint64_t rays;          /* bounce-loop iterations, the reference's ++raycount_ (cpu_trace.cpp:115-116) */
+    uint64_t samples;       /* camera paths */
+    uint64_t box_tests;     /* child-AABB slab tests (only counted by trh_render_stats) */
+    uint64_t tri_tests;     /* Moller-Trumbore tests  (only counted by trh_render_stats) */
+    uint64_t hits;          /* bounce iterations that hit geometry (trh_render_stats) */
+    uint64_t tex_fetches;   /* Texture::GetPixel calls (trh_render_stats) */
+    double   kernel_ms;     /* sum of HIP-event durations of render launches since last reset */
+    uint64_t launches;      /* number of trh_render calls timed in kernel_ms */
+} trh_stats;
+
+const char* trh_last_error(void);
+int trh_abi_version(void);
+int trh_device_count(int* count_out);
+
+/* Startup, device half. Replaces the device/context part of TracyModule::Startup
+ * (src/module.h:35; CUDA analogue CUDATraceKernel::Setup, cuda_trace.cu:227-260). */
+int trh_init(int device, trh_context** ctx_out);
+
+/* Shutdown (src/module.h:38; cuda_trace.cu:311-326). Frees all device memory. */
+int trh_shutdown(trh_context* ctx);
+
+/* Scene preprocessing + upload, once. Replaces CPUDetails::ProcessScene
+ * (cpu_details.cpp:26-86: acceleration-structure build) and CUDATraceKernel::SetupScene
+ * (cuda_trace.cu:262-309: deep copy to the device). Builds the module's own BVH on the
+ * host, lays nodes/triangles out in 64 B-aligned arrays and copies them to HBM. */
+int trh_scene_upload(trh_context* ctx, const trh_scene_desc* scene);
+
+/* Camera (re)upload. Replaces CUDATraceKernel::UpdateCamera (cuda_trace.cu:221-225).
+ * inv_view_proj is column-major, = inverse(projection * view) (src/camera.h:45,54).
+ * Does NOT reset the accumulation (call trh_reset_accumulation for a camera cut). */
+int trh_set_camera(trh_context* ctx, const float eye[3], const float inv_view_proj[16]);
+
+/* TracyEvent::eCameraCut handler (cpu_trace.cpp:72-82; cpu_details.h:90). */
+int trh_reset_accumulation(trh_context* ctx);
+
+int trh_set_pipeline(trh_context* ctx, int pipeline /* trh_pipeline */);
+
+/* THE HOT CALL. Replaces CpuTrace::OnUpdate + Trace (cpu_trace.cpp:33-170): traces
+ * samples [spp_begin, spp_begin+spp_count) of every pixel (one camera path each) and adds
+ * their radiance into the context's float4 accumulation buffer (rgb sum, .w = count).
+ * RNG state of sample s of pixel p is derived from (p, s, seed), then follows the
+ * reference's PCG fastrand sequence (src/random.h:66-77). Asynchronous on the context's
+ * stream; trh_synchronize / trh_resolve / trh_get_stats wait for it. */
+int trh_render(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, uint64_t seed);
+
+/* Same as trh_render but runs the instrumented kernel build that also counts box tests,
+ * triangle tests, hits and texture fetches (the roofline numerator). Slower. */
+int trh_render_stats(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, uint64_t seed);
+
+int trh_synchronize(trh_context* ctx);
+
+/* Device pointer of the accumulation buffer (width*height float4, rgb sums + count) so
+ * that a multi-GPU host can reduce it in place (RCCL / torch.distributed) before resolve. */
+int trh_accum_device_ptr(trh_context* ctx, void** dptr_out, size_t* nbytes_out);
+
+/* Makes the context accumulate into caller-owned device memory (width*height float4, 16-byte
+ * aligned, on the context's device) instead of its internal buffer, e.g. a torch tensor that
+ * torch.distributed / RCCL then reduces in place. The buffer is NOT cleared by this call.
+ * dptr == NULL re-binds the internal buffer. No counterpart in the reference (single device). */
+int trh_bind_accum_buffer(trh_context* ctx, void* dptr, size_t nbytes);
+
+/* Replaces CPUDetails::UpdateOutput's running mean (cpu_details.cpp:187-199) for the whole
+ * frame: mean = sum / count, on the device, into an internal float4 image (row 0 = bottom
+ * row, like the reference's output[]). If rgba_host != NULL the image is copied to the host
+ * (width*height*4 floats, .w = sample count). samples_out receives the samples per pixel
+ * accumulated since the last reset (as counted by this context). */
+int trh_resolve(trh_context* ctx, float* rgba_host, uint64_t* samples_out);
+
+/* Parity probe (a): nearest hit of the un-jittered primary ray through each pixel centre
+ * ((x+.5)/W, (y+.5)/H). ids[p] = (mesh << 24) | triangle (cpu_details.h:34), 0xffffffff on
+ * miss. t and uv (2 floats per pixel: Moller-Trumbore u,v) are optional (may be NULL). */
+int trh_primary_hits(trh_context* ctx, uint32_t* ids_host, float* t_host, float* uv_host);
+
+/* Parity probe (b): radiance of ONE sample index for every pixel (no accumulation),
+ * width*height*4 floats (.w = number of bounce iterations of that path). */
+int trh_sample_radiance(trh_context* ctx, uint32_t sample_index, uint64_t seed, float* rgba_host);
+
+/* Ray / sample counters. Replaces TracyModule::GetRayCount (src/module.h:53) with 64-bit
+ * counters (the reference's u32 wraps at GPU rates). */
+int trh_get_stats(trh_context* ctx, trh_stats* out, int reset);
+
+/* Info about the uploaded acceleration structure (for DESIGN/bench reporting). */
+typedef struct trh_bvh_info {
+    uint32_t node_count;
+    uint32_t tri_count;       /* triangles stored (after dropping nothing: == scene triangles) */
+    uint32_t max_depth;
+    uint32_t max_leaf_size;
+    uint64_t node_bytes;
+    uint64_t tri_bytes;
+    double   sah_cost;
+    double   build_ms;
+} trh_bvh_info;
+int trh_get_bvh_info(trh_context* ctx, trh_bvh_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACY_HIP_H */

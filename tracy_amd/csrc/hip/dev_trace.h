@@ -1,0 +1,312 @@
+// dev_trace.h -- device functions of the per-sample path-tracing hot path (gfx950).
+//
+// Reference behaviour restated for the GPU (citations into carcass82/tracy):
+//   fastrand                    src/random.h:71-77
+//   Camera::GetRayFrom          src/camera.h:28-35, Ray ctor src/ray.h:15-19
+//   collision::RayTriangle      src/collision.h:33-74   (back-face cull, EPS edge rejection, t ties)
+//   ComputeIntersection (tail)  cpu_details.cpp:169-182 (attribute interpolation, normal NOT normalised)
+//   Material::Scatter + getters src/material.h:125-268
+//   Texture::GetPixel           src/texture.h:50-57
+//   sky lookup + RR             cpu_trace.cpp:146-166
+// The traversal itself (stack walk over this module's own 64-byte BVH2 records) has no
+// counterpart in the reference: it replaces accel::IntersectsWithTree (src/kdtree.h:382-429).
+//
+// Arithmetic contract (DESIGN.md "Decreed arithmetic"): this file is compiled with
+// -ffp-contract=off; every fused multiply-add is an explicit __builtin_fmaf and appears only in
+// dot_f/cross_f (RayTriangle). Division and sqrt are IEEE (hipcc default).
+#pragma once
+#include "dev_types.h"
+
+#define DEVFN __device__ __forceinline__
+
+namespace dev {
+
+constexpr float PI = 3.1415926535897932f;
+constexpr float EPS = 1.e-8f;
+
+struct V3 { float x, y, z; };
+DEVFN V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEVFN V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEVFN V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEVFN V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEVFN V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DEVFN V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+DEVFN float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEVFN V3 cross(V3 a, V3 b) { return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+DEVFN V3 normalize(V3 v) { return v * (1.f / __builtin_sqrtf(dot(v, v))); }
+DEVFN float lerp(float x, float y, float a) { return x * (1.f - a) + y * a; }
+DEVFN V3 lerp(V3 x, V3 y, float a) { return x * (1.f - a) + y * a; }
+DEVFN V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2.f; }
+DEVFN V3 refract(V3 I, V3 N, float eta) {
+    const float d = dot(N, I);
+    const float k = 1.f - eta * eta * (1.f - d * d);
+    if (k >= 0.f) return eta * I - (eta * d + __builtin_sqrtf(k)) * N;
+    return mk(0.f, 0.f, 0.f);
+}
+// fused forms, RayTriangle only
+DEVFN float dot_f(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+DEVFN V3 cross_f(V3 a, V3 b) {
+    return mk(__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y)));
+}
+
+// ------------------------------------------------------------------ RNG (src/random.h:71-77)
+DEVFN float fastrand(uint32_t& ctx) {
+    const uint32_t state = ctx;
+    ctx = ctx * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    // x / float(UINT32_MAX): float(UINT32_MAX) rounds to 2^32, so this is an exact scaling
+    return (float)((word >> 22u) ^ word) * 2.3283064365386963e-10f;
+}
+DEVFN uint32_t pcg_hash(uint32_t v) {
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+// counter-based per-path state; seed_hash = pcg_hash(seed32) is computed once on the host
+DEVFN uint32_t path_rng_state(uint32_t pixel_index, uint32_t sample_index, uint32_t seed_hash) {
+    return pcg_hash(pixel_index ^ pcg_hash(sample_index ^ seed_hash));
+}
+
+struct Counters { uint32_t rays, box_tests, tri_tests, hits, tex_fetches; };
+
+struct Hit {
+    float t, u, v;
+    int prim;        // leaf-order primitive index, -1 = miss
+    uint32_t id;     // packed reference id (mesh << 24) | triangle
+};
+
+// ------------------------------------------------------------------ camera (src/camera.h:28-35)
+DEVFN void camera_ray(const DevScene& sc, float s, float t, V3& o, V3& d) {
+    const float nx = s * 2.f - 1.f, ny = t * 2.f - 1.f, nz = 1.f;
+    float p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a0 = sc.ivp[0 * 4 + i] * nx + sc.ivp[1 * 4 + i] * ny;
+        const float a1 = sc.ivp[2 * 4 + i] * nz + sc.ivp[3 * 4 + i] * 1.f;
+        p[i] = a0 + a1;
+    }
+    o = mk(sc.eye[0], sc.eye[1], sc.eye[2]);
+    d = normalize(mk(p[0] / p[3], p[1] / p[3], p[2] / p[3]) - o);
+}
+
+// ------------------------------------------------------------------ nearest hit
+// stack: this lane's LDS column, entry i at stack[i * TRH_BLOCK]
+template <bool STATS>
+DEVFN void intersect(const DevScene& sc, V3 o, V3 d, Hit& hit, int* __restrict__ stack, Counters& cnt) {
+    const V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // Ray ctor: rcp(direction)
+    hit.t = 3.402823466e+38f;  // HitData.t = FLT_MAX (cpu_trace.cpp:119)
+    hit.u = hit.v = 0.f;
+    hit.prim = -1;
+    hit.id = TRH_MISS_ID;
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+        // ---- inner records: one 64-byte fetch, two slab tests
+        while (node >= 0) {
+            const float4 n0 = sc.nodes[node * 4 + 0];
+            const float4 n1 = sc.nodes[node * 4 + 1];
+            const float4 nz = sc.nodes[node * 4 + 2];
+            const float4 lk = sc.nodes[node * 4 + 3];
+            if (STATS) cnt.box_tests += 2;
+            const float ax0 = (n0.x - o.x) * inv.x, ax1 = (n0.y - o.x) * inv.x;
+            const float ay0 = (n0.z - o.y) * inv.y, ay1 = (n0.w - o.y) * inv.y;
+            const float az0 = (nz.x - o.z) * inv.z, az1 = (nz.y - o.z) * inv.z;
+            const float bx0 = (n1.x - o.x) * inv.x, bx1 = (n1.y - o.x) * inv.x;
+            const float by0 = (n1.z - o.y) * inv.y, by1 = (n1.w - o.y) * inv.y;
+            const float bz0 = (nz.z - o.z) * inv.z, bz1 = (nz.w - o.z) * inv.z;
+            const float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.f));
+            const float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), hit.t));
+            const float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.f));
+            const float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), hit.t));
+            const bool h0 = tmin0 <= tmax0;
+            const bool h1 = tmin1 <= tmax1;
+            const int c0 = __float_as_int(lk.x), c1 = __float_as_int(lk.y);
+            if (h0 && h1) {
+                const bool swp = tmin1 < tmin0;
+                node = swp ? c1 : c0;
+                stack[sp * TRH_BLOCK] = swp ? c0 : c1;
+                ++sp;
+            } else if (h0 || h1) {
+                node = h0 ? c0 : c1;
+            } else {
+                if (sp == 0) return;
+                --sp;
+                node = stack[sp * TRH_BLOCK];
+            }
+        }
+        // ---- leaf: Moller-Trumbore over count 48-byte records (collision.h:33-74)
+        const uint32_t bits = ~(uint32_t)node;
+        const uint32_t first = bits >> 4, count = bits & 15u;
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t p = first + i;
+            const float4 r0 = sc.tris[p * 3 + 0];
+            const float4 r1 = sc.tris[p * 3 + 1];
+            const float4 r2 = sc.tris[p * 3 + 2];
+            if (STATS) cnt.tri_tests += 1;
+            const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z);
+            const uint32_t id = __float_as_uint(r0.w);
+            const V3 pvec = cross_f(d, e2);
+            const V3 tvec = o - v0;
+            const float det = dot_f(e1, pvec);
+            const float u = dot_f(tvec, pvec);
+            const V3 qvec = cross_f(tvec, e1);
+            const float v = dot_f(d, qvec);
+            bool ok = !(det < EPS) && !(u < EPS || u > det) && !(v < EPS || u + v > det);
+            if (ok) {
+                const float rdet = 1.f / det;
+                const float t = dot_f(e2, qvec) * rdet;
+                // reference: reject t < EPS || t > RayT; an equal t replaces (last tested wins). Without the
+                // reference's test order, exact ties go to the larger packed id (documented in DESIGN.md).
+                if (!(t < EPS) && (t < hit.t || (t == hit.t && id > hit.id))) {
+                    hit.t = t;
+                    hit.u = u * rdet;
+                    hit.v = v * rdet;
+                    hit.prim = (int)p;
+                    hit.id = id;
+                }
+            }
+        }
+        if (sp == 0) return;
+        --sp;
+        node = stack[sp * TRH_BLOCK];
+    }
+}
+
+// ------------------------------------------------------------------ textures (src/texture.h:50-57)
+template <bool STATS>
+DEVFN float4 get_pixel(const DevScene& sc, uint32_t tex, float u, float v, Counters& cnt) {
+    const DevTexture t = sc.textures[tex];
+    if (STATS) cnt.tex_fetches += 1;
+    const float fw = (float)t.width, fh = (float)t.height;
+    const float fu = u - floorf(u);
+    const float w1 = 1.f - v;
+    const float fv = w1 - floorf(w1);
+    // clamp(x, 0, n-1) then u32 conversion; a NaN index is 0 (fmaxf drops the NaN)
+    const uint32_t i = (uint32_t)fminf(fmaxf(fu * fw, 0.f), fw - 1.f);
+    const uint32_t j = (uint32_t)fminf(fmaxf(fv * fh, 0.f), fh - 1.f);
+    return t.texels[(size_t)j * (size_t)t.width + i];
+}
+
+DEVFN float pow2(float x) { return x * x; }
+DEVFN float pow5(float x) { const float x2 = x * x; return x2 * x2 * x; }
+DEVFN float schlick(float c, float ref_idx) {
+    const float r0 = pow2((1.f - ref_idx) / (1.f + ref_idx));
+    return r0 + (1.f - r0) * pow5(1.f - c);
+}
+
+struct PathState {
+    V3 o, d;            // current ray
+    V3 throughput;
+    V3 radiance;        // "pixel" of CpuTrace::Trace
+    uint32_t rng;
+    uint32_t bounce;    // iterations done so far
+};
+
+// One iteration of the bounce loop of CpuTrace::Trace (cpu_trace.cpp:113-167) AFTER the
+// intersection: shading, sky, Russian roulette. Returns true if the path continues.
+template <bool STATS>
+DEVFN bool shade(const DevScene& sc, PathState& ps, const Hit& hit, Counters& cnt) {
+    cnt.rays += 1;  // ++raycount_ (cpu_trace.cpp:115-116)
+    ps.bounce += 1;
+    if (hit.prim >= 0) {
+        if (STATS) cnt.hits += 1;
+        // ---- attribute interpolation (cpu_details.cpp:169-182)
+        const float4 s0 = sc.shade[hit.prim * 4 + 0];
+        const float4 s1 = sc.shade[hit.prim * 4 + 1];
+        const float4 s2 = sc.shade[hit.prim * 4 + 2];
+        const float4 s3 = sc.shade[hit.prim * 4 + 3];
+        const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
+        const float w = 1.f - hit.u - hit.v;
+        const V3 point = ps.o + hit.t * ps.d;
+        V3 normal = w * n0 + hit.u * n1 + hit.v * n2;
+        const float tu = w * s2.y + hit.u * s2.w + hit.v * s3.y;
+        const float tv = w * s2.z + hit.u * s3.x + hit.v * s3.z;
+        const DevMaterial m = sc.materials[__float_as_uint(s3.w)];
+
+        // ---- texture-or-constant (src/material.h:164-203), in Scatter's order (:217-221)
+        V3 emissive = mk(m.emissive[0], m.emissive[1], m.emissive[2]);
+        if (m.tex[4] != TRH_MISS_ID) { const float4 p = get_pixel<STATS>(sc, m.tex[4], tu, tv, cnt); emissive = mk(p.x, p.y, p.z); }
+        float metalness = m.metalness;
+        if (m.tex[3] != TRH_MISS_ID) metalness = get_pixel<STATS>(sc, m.tex[3], tu, tv, cnt).x;
+        V3 basecolor = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+        if (m.tex[0] != TRH_MISS_ID) { const float4 p = get_pixel<STATS>(sc, m.tex[0], tu, tv, cnt); basecolor = mk(p.x, p.y, p.z); }
+        float roughness = m.roughness;
+        if (m.tex[2] != TRH_MISS_ID) roughness = get_pixel<STATS>(sc, m.tex[2], tu, tv, cnt).x;
+        if (m.tex[1] != TRH_MISS_ID) {
+            const float4 t0 = sc.tangents[hit.prim * 3 + 0];
+            const float4 t1 = sc.tangents[hit.prim * 3 + 1];
+            const float4 t2 = sc.tangents[hit.prim * 3 + 2];
+            const V3 tangent = w * mk(t0.x, t0.y, t0.z) + hit.u * mk(t0.w, t1.x, t1.y) + hit.v * mk(t1.z, t1.w, t2.x);
+            const float4 p = get_pixel<STATS>(sc, m.tex[1], tu, tv, cnt);
+            const V3 nm = mk(p.x * 2.f - 1.f, p.y * 2.f - 1.f, p.z * 2.f - 1.f);
+            const V3 bitangent = cross(normal, normalize(tangent - dot(tangent, normal) * normal));
+            normal = normalize(bitangent * nm.x + tangent * nm.y + normal * nm.z);
+        }
+
+        // ---- Material::Scatter (src/material.h:210-268)
+        const V3 raydir = ps.d;
+        const float VdotN = dot(raydir, normal);
+        const float z = 2.f * fastrand(ps.rng) - 1.f;
+        const float phi = 2.f * PI * fastrand(ps.rng);
+        const float r = __builtin_sqrtf(1.f - pow2(z));
+        const V3 scattered = normal + mk(r * cosf(phi), r * sinf(phi), z);
+        const V3 reflected = reflect(raydir, normal);
+        const V3 specular = lerp(reflected, scattered, roughness);
+        V3 dir, attenuation;
+        if (m.translucent > EPS) {  // BTDF
+            const bool inside = VdotN > EPS;
+            const float cosine = inside ? __builtin_sqrtf(1.f - pow2(m.ior) * (1.f - pow2(VdotN))) : -VdotN;
+            const float ior = inside ? m.ior : 1.f / m.ior;
+            const V3 refracted = refract(raydir, normal, ior);
+            const V3 transmitted = lerp(refracted, scattered, roughness);
+            const bool is_specular = fastrand(ps.rng) < schlick(cosine, ior);
+            dir = is_specular ? specular : transmitted;
+            attenuation = basecolor;
+        } else {  // BRDF
+            const V3 specularcolor = lerp(mk(.85f, .85f, .85f), basecolor, metalness);
+            const float materialspecularchance = lerp(.1f, 1.f, metalness);
+            const float fresnelspecularchance = lerp(materialspecularchance, 1.f, (1.f - roughness) * schlick(-VdotN, 1.f));
+            const bool is_specular = fastrand(ps.rng) < fresnelspecularchance;
+            dir = is_specular ? specular : scattered;
+            attenuation = is_specular ? specularcolor : basecolor;
+        }
+        dir = normalize(dir);
+        ps.o = point + 0.001f * dir;
+        ps.d = dir;
+        ps.radiance = ps.radiance + emissive * ps.throughput;  // cpu_trace.cpp:141
+        ps.throughput = ps.throughput * attenuation;           // cpu_trace.cpp:143
+    } else {
+        // ---- sky (cpu_trace.cpp:146-156)
+        const DevMaterial sky = sc.materials[0];
+        V3 emission = mk(sky.emissive[0], sky.emissive[1], sky.emissive[2]);
+        if (sky.tex[4] != TRH_MISS_ID) {
+            const float su = atan2f(ps.d.z, ps.d.x) / (2 * PI) + 0.5f;
+            const float sv = asinf(ps.d.y) / PI + 0.5f;
+            const float4 p = get_pixel<STATS>(sc, sky.tex[4], su, sv, cnt);
+            emission = mk(p.x, p.y, p.z);
+        }
+        ps.radiance = ps.radiance + emission * ps.throughput;
+        return false;
+    }
+    if (ps.bounce >= sc.max_bounces) return false;  // for (t < kMaxBounces)
+    if (sc.flags & 1u) {  // USE_RUSSIAN_ROULETTE (cpu_trace.cpp:158-166)
+        const float p = EPS + fmaxf(ps.throughput.x, fmaxf(ps.throughput.y, ps.throughput.z));
+        if (fastrand(ps.rng) > p) return false;
+        ps.throughput = ps.throughput * (1.f / p);
+    }
+    return true;
+}
+
+// start of a camera path: RNG state, jitter, primary ray (cpu_trace.cpp:59-63)
+DEVFN void generate(const DevScene& sc, PathState& ps, int px, int py, uint32_t sample, uint32_t seed_hash) {
+    const uint32_t pixel = (uint32_t)(py * sc.width + px);
+    ps.rng = path_rng_state(pixel, sample, seed_hash);
+    const float u = ((float)px + fastrand(ps.rng)) / (float)sc.width;
+    const float v = ((float)py + fastrand(ps.rng)) / (float)sc.height;
+    camera_ray(sc, u, v, ps.o, ps.d);
+    ps.throughput = mk(1.f, 1.f, 1.f);
+    ps.radiance = mk(0.f, 0.f, 0.f);
+    ps.bounce = 0;
+}
+
+}  // namespace dev

@@ -1,0 +1,55 @@
+// dev_types.h -- POD types shared by the host side of the C ABI and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TRH_STACK_SIZE 32      // LDS traversal-stack entries per lane == bvh::kMaxDepth
+#define TRH_BLOCK 256          // threads per workgroup (4 wave64)
+#define TRH_WAVES_PER_BLOCK (TRH_BLOCK / 64)
+#define TRH_MISS_ID 0xffffffffu
+
+// 64-byte material record (src/material.h:103-117 restated as POD)
+struct DevMaterial {
+    float albedo[3];
+    float roughness;
+    float metalness;
+    float ior;
+    float emissive[3];
+    float translucent;
+    uint32_t tex[5];   // basecolor, normal, roughness, metalness, emissive; 0xffffffff = none
+    uint32_t pad;
+};
+static_assert(sizeof(DevMaterial) == 64, "DevMaterial must be one 64-byte record");
+
+struct DevTexture {
+    const float4* texels;   // RGBA32F, row 0 first (src/texture.h:90)
+    int32_t width;
+    int32_t height;
+};
+
+// Everything a kernel needs, passed by value as a kernel argument.
+struct DevScene {
+    const float4* nodes;       // 4 float4 per inner-node record (see bvh_builder.h)
+    const float4* tris;        // 3 float4 per primitive, leaf order: (v0, id) (e1, 0) (e2, 0)
+    const float4* shade;       // 4 float4 per primitive: n0 n1 n2 (9) uv0 uv1 uv2 (6) material (1)
+    const float4* tangents;    // 3 float4 per primitive (t0 t1 t2), NULL if no normal map is used
+    const DevMaterial* materials;
+    const DevTexture* textures;
+    int32_t width, height;
+    uint32_t max_bounces;
+    uint32_t flags;
+    float eye[3];
+    float ivp[16];             // column-major inverse(projection * view)
+};
+
+struct RenderParams {
+    uint32_t spp_begin;
+    uint32_t spp_count;
+    uint32_t seed32;
+    uint32_t tiles_x, tiles_y;
+};
+
+// device-side counters, one cache line
+struct DevCounters {
+    unsigned long long rays, samples, box_tests, tri_tests, hits, tex_fetches, pad0, pad1;
+};

@@ -1,0 +1,617 @@
+// tracy_hip.hip -- gfx950 kernels and the C ABI of include/tracy_hip.h.
+//
+// Kernels (all hand-written HIP for CDNA4, wave64):
+//   k_megakernel<STATS>   persistent waves pull 8x8-pixel tiles; every lane owns one pixel and
+//                         regenerates its next sample in place as soon as its path ends, so the
+//                         traversal loop stays full until the tile's samples run out.
+//   k_primary_hits        parity probe (a): nearest hit of un-jittered pixel-centre rays.
+//   k_sample_radiance     parity probe (b): radiance of one sample index per pixel.
+//   k_resolve             mean = sum / count (CPUDetails::UpdateOutput, cpu_details.cpp:187-199).
+// Traversal stacks live in LDS (32 entries x 256 lanes x 4 B = 32 KiB per workgroup), column
+// per lane so that ds_read/ds_write_b32 are bank-conflict free at any stack depth.
+#include "../../../include/tracy_hip.h"
+#include "../host/bvh_builder.h"
+#include "dev_trace.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace dev;
+
+// =====================================================================================
+// kernels
+// =====================================================================================
+
+DEVFN uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool STATS>
+DEVFN void flush_counters(const Counters& c, DevCounters* g) {
+    const uint32_t rays = wave_sum(c.rays);
+    uint32_t bt = 0, tt = 0, hh = 0, tf = 0;
+    if (STATS) { bt = wave_sum(c.box_tests); tt = wave_sum(c.tri_tests); hh = wave_sum(c.hits); tf = wave_sum(c.tex_fetches); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g->rays, (unsigned long long)rays);
+        if (STATS) {
+            atomicAdd(&g->box_tests, (unsigned long long)bt);
+            atomicAdd(&g->tri_tests, (unsigned long long)tt);
+            atomicAdd(&g->hits, (unsigned long long)hh);
+            atomicAdd(&g->tex_fetches, (unsigned long long)tf);
+        }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
+                                                          DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
+    __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
+    int* stack = &s_stack[threadIdx.x];
+    const int lane = threadIdx.x & 63;
+    const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
+    const uint32_t seed_hash = rp.seed32;
+    Counters cnt = {0, 0, 0, 0, 0};
+
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(tile_counter, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= ntiles) break;  // wave-uniform exit: every wave reaches it
+        const int px = (int)(tile % rp.tiles_x) * 8 + (lane & 7);
+        const int py = (int)(tile / rp.tiles_x) * 8 + (lane >> 3);
+        const bool valid = px < sc.width && py < sc.height;
+        uint32_t s = rp.spp_begin;
+        const uint32_t end = valid ? rp.spp_begin + rp.spp_count : rp.spp_begin;
+        V3 acc = mk(0.f, 0.f, 0.f);
+        PathState ps;
+        ps.o = ps.d = ps.throughput = ps.radiance = mk(0.f, 0.f, 0.f);
+        ps.rng = 0;
+        ps.bounce = 0;
+        bool alive = false;
+        for (;;) {
+            if (!alive && s < end) {
+                generate(sc, ps, px, py, s, seed_hash);
+                alive = true;
+            }
+            if (__ballot(alive) == 0ull) break;
+            if (alive) {
+                Hit hit;
+                intersect<STATS>(sc, ps.o, ps.d, hit, stack, cnt);
+                alive = shade<STATS>(sc, ps, hit, cnt);
+                if (!alive) {
+                    acc = acc + ps.radiance;  // samples are summed in increasing sample index
+                    ++s;
+                }
+            }
+        }
+        if (valid) {
+            const size_t p = (size_t)py * sc.width + px;
+            float4 a = accum[p];
+            a.x += acc.x; a.y += acc.y; a.z += acc.z; a.w += (float)rp.spp_count;
+            accum[p] = a;
+        }
+    }
+    flush_counters<STATS>(cnt, counters);
+}
+
+__global__ __launch_bounds__(TRH_BLOCK) void k_primary_hits(DevScene sc, uint32_t* __restrict__ ids, float* __restrict__ t_out, float2* __restrict__ uv_out) {
+    __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
+    int* stack = &s_stack[threadIdx.x];
+    const uint32_t p = blockIdx.x * TRH_BLOCK + threadIdx.x;
+    if (p >= (uint32_t)(sc.width * sc.height)) return;
+    const int px = (int)(p % (uint32_t)sc.width), py = (int)(p / (uint32_t)sc.width);
+    const float u = ((float)px + 0.5f) / (float)sc.width;
+    const float v = ((float)py + 0.5f) / (float)sc.height;
+    V3 o, d;
+    camera_ray(sc, u, v, o, d);
+    Hit hit;
+    Counters cnt = {0, 0, 0, 0, 0};
+    intersect<false>(sc, o, d, hit, stack, cnt);
+    ids[p] = hit.id;
+    t_out[p] = hit.t;
+    uv_out[p] = make_float2(hit.u, hit.v);
+}
+
+__global__ __launch_bounds__(TRH_BLOCK) void k_sample_radiance(DevScene sc, uint32_t sample, uint32_t seed_hash, float4* __restrict__ out) {
+    __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
+    int* stack = &s_stack[threadIdx.x];
+    const uint32_t p = blockIdx.x * TRH_BLOCK + threadIdx.x;
+    if (p >= (uint32_t)(sc.width * sc.height)) return;
+    const int px = (int)(p % (uint32_t)sc.width), py = (int)(p / (uint32_t)sc.width);
+    PathState ps;
+    generate(sc, ps, px, py, sample, seed_hash);
+    Counters cnt = {0, 0, 0, 0, 0};
+    bool alive = true;
+    while (alive) {
+        Hit hit;
+        intersect<false>(sc, ps.o, ps.d, hit, stack, cnt);
+        alive = shade<false>(sc, ps, hit, cnt);
+    }
+    out[p] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, (float)ps.bounce);
+}
+
+__global__ void k_resolve(const float4* __restrict__ accum, float4* __restrict__ out, uint32_t n) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 a = accum[p];
+    const float inv = a.w > 0.f ? 1.f / a.w : 0.f;
+    out[p] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w);
+}
+
+// =====================================================================================
+// host side of the C ABI
+// =====================================================================================
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                           \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) return fail(TRH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+uint32_t host_pcg_hash(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+uint32_t seed_hash_of(uint64_t seed) {
+    const uint32_t seed32 = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u);
+    return host_pcg_hash(seed32);
+}
+
+}  // namespace
+
+struct trh_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    int pipeline = TRH_PIPELINE_MEGAKERNEL;
+    bool has_scene = false;
+    bool has_camera = false;
+    DevScene sc{};
+    std::vector<void*> allocs;  // everything freed at shutdown / re-upload
+    float4* accum = nullptr;          // buffer in use (internal or caller-bound)
+    float4* accum_internal = nullptr;
+    float4* resolved = nullptr;
+    DevCounters* counters = nullptr;
+    unsigned int* tile_counter = nullptr;
+    uint64_t samples = 0;        // since the last stats reset
+    uint64_t accum_spp = 0;      // samples per pixel in the accumulation buffer
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // render launches not yet timed
+    double kernel_ms = 0.0;
+    uint64_t launches = 0;
+    trh_bvh_info bvh{};
+    int mega_grid = 0, mega_grid_stats = 0;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc_copy(trh_context* c, const T* host, size_t count, T** out) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    c->allocs.push_back(p);
+    if (count) HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = (T*)p;
+    return TRH_OK;
+}
+
+int free_scene(trh_context* c) {
+    for (void* p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    c->accum = nullptr;
+    c->accum_internal = nullptr;
+    c->resolved = nullptr;
+    c->has_scene = false;
+    return TRH_OK;
+}
+
+int collect_timings(trh_context* c) {
+    for (auto& pr : c->pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(pr.second));
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->kernel_ms += ms;
+        c->launches += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    c->pending.clear();
+    return TRH_OK;
+}
+
+template <bool STATS>
+int launch_megakernel(trh_context* c, const RenderParams& rp) {
+    int& grid = STATS ? c->mega_grid_stats : c->mega_grid;
+    if (grid == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS>, TRH_BLOCK, 0));
+        if (per_cu < 1) per_cu = 1;
+        grid = per_cu * c->num_cus;
+    }
+    HIP_TRY(hipMemsetAsync(c->tile_counter, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(k_megakernel<STATS>, dim3(grid), dim3(TRH_BLOCK), 0, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
+    HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed, bool stats) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_render: ctx is NULL");
+    if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_render: scene and camera must be uploaded first");
+    if (spp_count == 0) return TRH_OK;
+    if ((uint64_t)spp_begin + spp_count > 0xffffffffull) return fail(TRH_ERR_LIMIT, "trh_render: sample index exceeds 32 bits");
+    HIP_TRY(hipSetDevice(c->device));
+    RenderParams rp{};
+    rp.spp_begin = spp_begin;
+    rp.spp_count = spp_count;
+    rp.seed32 = seed_hash_of(seed);
+    rp.tiles_x = (uint32_t)(c->sc.width + 7) / 8;
+    rp.tiles_y = (uint32_t)(c->sc.height + 7) / 8;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    int rc = stats ? launch_megakernel<true>(c, rp) : launch_megakernel<false>(c, rp);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    c->pending.emplace_back(e0, e1);
+    c->samples += (uint64_t)c->sc.width * c->sc.height * spp_count;
+    c->accum_spp += spp_count;
+    if (c->pending.size() > 4096) return collect_timings(c);
+    return TRH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* trh_last_error(void) { return g_err.c_str(); }
+int trh_abi_version(void) { return TRH_ABI_VERSION; }
+
+int trh_device_count(int* count_out) {
+    if (!count_out) return fail(TRH_ERR_INVALID_ARG, "trh_device_count: NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count_out = 0; return fail(TRH_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count_out = n;
+    return TRH_OK;
+}
+
+int trh_init(int device, trh_context** ctx_out) {
+    if (!ctx_out) return fail(TRH_ERR_INVALID_ARG, "trh_init: ctx_out is NULL");
+    *ctx_out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(TRH_ERR_NO_DEVICE, "trh_init: no HIP device (this module has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(TRH_ERR_INVALID_ARG, "trh_init: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    auto* c = new trh_context();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(TRH_ERR_HIP, "hipStreamCreate failed"); }
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(DevCounters)) != hipSuccess) { delete c; return fail(TRH_ERR_HIP, "hipMalloc(counters) failed"); }
+    c->counters = (DevCounters*)p;
+    (void)hipMemset(p, 0, sizeof(DevCounters));
+    if (hipMalloc(&p, 256) != hipSuccess) { delete c; return fail(TRH_ERR_HIP, "hipMalloc(tile counter) failed"); }
+    c->tile_counter = (unsigned int*)p;
+    (void)hipMemset(p, 0, 256);
+    *ctx_out = c;
+    return TRH_OK;
+}
+
+int trh_shutdown(trh_context* c) {
+    if (!c) return TRH_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)collect_timings(c);
+    free_scene(c);
+    (void)hipFree(c->counters);
+    (void)hipFree(c->tile_counter);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TRH_OK;
+}
+
+int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
+    if (!c || !d) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: NULL argument");
+    if (d->width == 0 || d->height == 0) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: empty frame");
+    if (d->mesh_count > 256) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 256 meshes (8-bit mesh id)");
+    if (d->material_count == 0) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: material 0 (sky) is required");
+    if ((uint64_t)d->width * d->height > (1ull << 31)) return fail(TRH_ERR_LIMIT, "trh_scene_upload: frame too large");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_scene(c);
+
+    // ---- validate + flatten triangles (world space; the reference bakes transforms at load)
+    std::vector<bvh::InputTriangle> tris;
+    tris.reserve(d->index_count / 3);
+    bool any_normal_map = false;
+    for (uint32_t m = 0; m < d->material_count; ++m) {
+        for (int k = 0; k < TRH_TEX_COUNT; ++k) {
+            const uint32_t t = d->materials[m].tex[k];
+            if (t != TRH_NO_TEXTURE && t >= d->texture_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: material references a missing texture");
+        }
+        if (d->materials[m].tex[TRH_TEX_NORMAL] != TRH_NO_TEXTURE) any_normal_map = true;
+    }
+    for (uint32_t m = 0; m < d->mesh_count; ++m) {
+        const trh_mesh& me = d->meshes[m];
+        if ((uint64_t)me.first_vertex + me.vertex_count > d->vertex_count || (uint64_t)me.first_index + me.index_count > d->index_count)
+            return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: mesh range out of bounds");
+        if (me.material >= d->material_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: mesh material out of range");
+        if (me.index_count / 3 > 0xffffffu) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 2^24 triangles in one mesh");
+        for (uint32_t t = 0; t < me.index_count / 3; ++t) {
+            bvh::InputTriangle it;
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t li = d->indices[me.first_index + t * 3 + k];
+                if (li >= me.vertex_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: vertex index out of range");
+                const float* v = d->vertices + (size_t)(me.first_vertex + li) * TRH_VERTEX_FLOATS;
+                float* dst = k == 0 ? it.v0 : (k == 1 ? it.v1 : it.v2);
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+            }
+            it.packed_id = (m << 24) | t;
+            tris.push_back(it);
+        }
+    }
+    if (tris.size() >= (1u << 27)) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 2^27 triangles");
+
+    // ---- build the BVH on the host
+    const auto t0 = std::chrono::steady_clock::now();
+    bvh::Result r;
+    bvh::build(tris, r);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (r.max_depth > (uint32_t)TRH_STACK_SIZE) return fail(TRH_ERR_LIMIT, "trh_scene_upload: BVH deeper than the traversal stack");
+
+    // ---- per-primitive shading records in leaf order
+    const size_t nprim = r.prim_index.size();
+    std::vector<float> shade(nprim * 16), tang(any_normal_map ? nprim * 12 : 0);
+    for (size_t p = 0; p < nprim; ++p) {
+        const uint32_t pid = tris[r.prim_index[p]].packed_id;
+        const uint32_t m = pid >> 24, t = pid & 0xffffffu;
+        const trh_mesh& me = d->meshes[m];
+        const float* vv[3];
+        for (int k = 0; k < 3; ++k) vv[k] = d->vertices + (size_t)(me.first_vertex + d->indices[me.first_index + t * 3 + k]) * TRH_VERTEX_FLOATS;
+        float* s = &shade[p * 16];
+        for (int k = 0; k < 3; ++k) { s[k * 3 + 0] = vv[k][3]; s[k * 3 + 1] = vv[k][4]; s[k * 3 + 2] = vv[k][5]; }
+        for (int k = 0; k < 3; ++k) { s[9 + k * 2] = vv[k][6]; s[9 + k * 2 + 1] = vv[k][7]; }
+        memcpy(&s[15], &me.material, 4);
+        if (any_normal_map) {
+            float* tg = &tang[p * 12];
+            for (int k = 0; k < 3; ++k) { tg[k * 3 + 0] = vv[k][8]; tg[k * 3 + 1] = vv[k][9]; tg[k * 3 + 2] = vv[k][10]; }
+            tg[9] = tg[10] = tg[11] = 0.f;
+        }
+    }
+
+    // ---- upload
+    DevScene sc{};
+    float* dp = nullptr;
+    int rc;
+    if ((rc = dev_alloc_copy(c, r.nodes.data(), r.nodes.size(), &dp))) return rc;
+    sc.nodes = (const float4*)dp;
+    if ((rc = dev_alloc_copy(c, r.tris.data(), r.tris.size(), &dp))) return rc;
+    sc.tris = (const float4*)dp;
+    if ((rc = dev_alloc_copy(c, shade.data(), shade.size(), &dp))) return rc;
+    sc.shade = (const float4*)dp;
+    if (any_normal_map) {
+        if ((rc = dev_alloc_copy(c, tang.data(), tang.size(), &dp))) return rc;
+        sc.tangents = (const float4*)dp;
+    }
+    std::vector<DevMaterial> mats(d->material_count);
+    for (uint32_t m = 0; m < d->material_count; ++m) {
+        const trh_material& s = d->materials[m];
+        DevMaterial& o = mats[m];
+        memcpy(o.albedo, s.albedo, 12);
+        o.roughness = s.roughness; o.metalness = s.metalness; o.ior = s.ior;
+        memcpy(o.emissive, s.emissive, 12);
+        o.translucent = s.translucent;
+        memcpy(o.tex, s.tex, sizeof(o.tex));
+        o.pad = 0;
+    }
+    DevMaterial* dm = nullptr;
+    if ((rc = dev_alloc_copy(c, mats.data(), mats.size(), &dm))) return rc;
+    sc.materials = dm;
+    std::vector<DevTexture> texs(d->texture_count);
+    for (uint32_t t = 0; t < d->texture_count; ++t) {
+        const trh_texture& s = d->textures[t];
+        if (!s.rgba || !s.width || !s.height) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: empty texture");
+        float* px = nullptr;
+        if ((rc = dev_alloc_copy(c, s.rgba, (size_t)s.width * s.height * 4, &px))) return rc;
+        texs[t].texels = (const float4*)px;
+        texs[t].width = (int32_t)s.width;
+        texs[t].height = (int32_t)s.height;
+    }
+    DevTexture* dt = nullptr;
+    if ((rc = dev_alloc_copy(c, texs.data(), texs.size(), &dt))) return rc;
+    sc.textures = dt;
+    sc.width = (int32_t)d->width;
+    sc.height = (int32_t)d->height;
+    sc.max_bounces = d->max_bounces ? d->max_bounces : 1;
+    sc.flags = d->flags;
+    // keep the camera if one was set before (re-upload of a scene)
+    memcpy(sc.eye, c->sc.eye, sizeof(sc.eye));
+    memcpy(sc.ivp, c->sc.ivp, sizeof(sc.ivp));
+
+    const size_t npix = (size_t)d->width * d->height;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, npix * sizeof(float4)));
+    c->allocs.push_back(p);
+    c->accum = c->accum_internal = (float4*)p;
+    HIP_TRY(hipMemset(p, 0, npix * sizeof(float4)));
+    HIP_TRY(hipMalloc(&p, npix * sizeof(float4)));
+    c->allocs.push_back(p);
+    c->resolved = (float4*)p;
+    HIP_TRY(hipMemset(p, 0, npix * sizeof(float4)));
+
+    c->sc = sc;
+    c->has_scene = true;
+    c->samples = 0;
+    c->accum_spp = 0;
+    c->bvh.node_count = (uint32_t)(r.nodes.size() / 16);
+    c->bvh.tri_count = (uint32_t)nprim;
+    c->bvh.max_depth = r.max_depth;
+    c->bvh.max_leaf_size = r.max_leaf;
+    c->bvh.node_bytes = r.nodes.size() * 4;
+    c->bvh.tri_bytes = r.tris.size() * 4;
+    c->bvh.sah_cost = r.sah_cost;
+    c->bvh.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    return TRH_OK;
+}
+
+int trh_set_camera(trh_context* c, const float eye[3], const float inv_view_proj[16]) {
+    if (!c || !eye || !inv_view_proj) return fail(TRH_ERR_INVALID_ARG, "trh_set_camera: NULL argument");
+    memcpy(c->sc.eye, eye, 12);
+    memcpy(c->sc.ivp, inv_view_proj, 64);
+    c->has_camera = true;
+    return TRH_OK;
+}
+
+int trh_reset_accumulation(trh_context* c) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_reset_accumulation: ctx is NULL");
+    if (!c->has_scene) return fail(TRH_ERR_STATE, "trh_reset_accumulation: no scene");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)c->sc.width * c->sc.height * sizeof(float4), c->stream));
+    c->accum_spp = 0;
+    return TRH_OK;
+}
+
+int trh_set_pipeline(trh_context* c, int pipeline) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: ctx is NULL");
+    if (pipeline != TRH_PIPELINE_MEGAKERNEL) return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: unknown pipeline");
+    c->pipeline = pipeline;
+    return TRH_OK;
+}
+
+int trh_render(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed) { return render_impl(c, spp_begin, spp_count, seed, false); }
+int trh_render_stats(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed) { return render_impl(c, spp_begin, spp_count, seed, true); }
+
+int trh_synchronize(trh_context* c) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_synchronize: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TRH_OK;
+}
+
+int trh_accum_device_ptr(trh_context* c, void** dptr_out, size_t* nbytes_out) {
+    if (!c || !dptr_out) return fail(TRH_ERR_INVALID_ARG, "trh_accum_device_ptr: NULL argument");
+    if (!c->has_scene) return fail(TRH_ERR_STATE, "trh_accum_device_ptr: no scene");
+    *dptr_out = c->accum;
+    if (nbytes_out) *nbytes_out = (size_t)c->sc.width * c->sc.height * sizeof(float4);
+    return TRH_OK;
+}
+
+int trh_bind_accum_buffer(trh_context* c, void* dptr, size_t nbytes) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_bind_accum_buffer: ctx is NULL");
+    if (!c->has_scene) return fail(TRH_ERR_STATE, "trh_bind_accum_buffer: no scene");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!dptr) { c->accum = c->accum_internal; return TRH_OK; }
+    const size_t need = (size_t)c->sc.width * c->sc.height * sizeof(float4);
+    if (nbytes < need) return fail(TRH_ERR_INVALID_ARG, "trh_bind_accum_buffer: buffer smaller than width*height*16 bytes");
+    if (((uintptr_t)dptr & 15u) != 0) return fail(TRH_ERR_INVALID_ARG, "trh_bind_accum_buffer: buffer must be 16-byte aligned");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dptr) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != c->device) {
+        (void)hipGetLastError();
+        return fail(TRH_ERR_INVALID_ARG, "trh_bind_accum_buffer: not device memory of this context's device");
+    }
+    c->accum = (float4*)dptr;
+    return TRH_OK;
+}
+
+int trh_resolve(trh_context* c, float* rgba_host, uint64_t* samples_out) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_resolve: ctx is NULL");
+    if (!c->has_scene) return fail(TRH_ERR_STATE, "trh_resolve: no scene");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
+    hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, c->resolved, n);
+    HIP_TRY(hipGetLastError());
+    if (rgba_host) HIP_TRY(hipMemcpyAsync(rgba_host, c->resolved, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (samples_out) *samples_out = c->accum_spp;
+    return TRH_OK;
+}
+
+int trh_primary_hits(trh_context* c, uint32_t* ids_host, float* t_host, float* uv_host) {
+    if (!c || !ids_host) return fail(TRH_ERR_INVALID_ARG, "trh_primary_hits: NULL argument");
+    if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_primary_hits: scene and camera must be uploaded first");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
+    void *d_ids = nullptr, *d_t = nullptr, *d_uv = nullptr;
+    HIP_TRY(hipMalloc(&d_ids, (size_t)n * 4));
+    HIP_TRY(hipMalloc(&d_t, (size_t)n * 4));
+    HIP_TRY(hipMalloc(&d_uv, (size_t)n * 8));
+    hipLaunchKernelGGL(k_primary_hits, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, (uint32_t*)d_ids, (float*)d_t, (float2*)d_uv);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ids_host, d_ids, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && t_host) e = hipMemcpyAsync(t_host, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && uv_host) e = hipMemcpyAsync(uv_host, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_ids); (void)hipFree(d_t); (void)hipFree(d_uv);
+    if (e != hipSuccess) return fail(TRH_ERR_HIP, std::string("trh_primary_hits: ") + hipGetErrorString(e));
+    return TRH_OK;
+}
+
+int trh_sample_radiance(trh_context* c, uint32_t sample_index, uint64_t seed, float* rgba_host) {
+    if (!c || !rgba_host) return fail(TRH_ERR_INVALID_ARG, "trh_sample_radiance: NULL argument");
+    if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_sample_radiance: scene and camera must be uploaded first");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
+    void* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, (size_t)n * sizeof(float4)));
+    hipLaunchKernelGGL(k_sample_radiance, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, sample_index, seed_hash_of(seed), (float4*)d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgba_host, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(TRH_ERR_HIP, std::string("trh_sample_radiance: ") + hipGetErrorString(e));
+    return TRH_OK;
+}
+
+int trh_get_stats(trh_context* c, trh_stats* out, int reset) {
+    if (!c || !out) return fail(TRH_ERR_INVALID_ARG, "trh_get_stats: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = collect_timings(c);
+    if (rc) return rc;
+    DevCounters h{};
+    HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+    out->rays = h.rays;
+    out->samples = c->samples;
+    out->box_tests = h.box_tests;
+    out->tri_tests = h.tri_tests;
+    out->hits = h.hits;
+    out->tex_fetches = h.tex_fetches;
+    out->kernel_ms = c->kernel_ms;
+    out->launches = c->launches;
+    if (reset) {
+        HIP_TRY(hipMemset(c->counters, 0, sizeof(DevCounters)));
+        c->samples = 0;
+        c->kernel_ms = 0.0;
+        c->launches = 0;
+    }
+    return TRH_OK;
+}
+
+int trh_get_bvh_info(trh_context* c, trh_bvh_info* out) {
+    if (!c || !out) return fail(TRH_ERR_INVALID_ARG, "trh_get_bvh_info: NULL argument");
+    if (!c->has_scene) return fail(TRH_ERR_STATE, "trh_get_bvh_info: no scene");
+    *out = c->bvh;
+    return TRH_OK;
+}
+
+}  // extern "C"

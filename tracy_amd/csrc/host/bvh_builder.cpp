@@ -1,0 +1,225 @@
+// bvh_builder.cpp -- binned-SAH BVH2 build, see bvh_builder.h for the layout.
+#include "bvh_builder.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace bvh {
+namespace {
+
+struct Box {
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    float mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const float p[3]) {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); }
+    }
+    void grow(const Box& b) {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); }
+    }
+    float half_area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx < 0.f || dy < 0.f || dz < 0.f) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Ref {
+    Box box;
+    float c[3];
+    uint32_t idx;
+};
+
+constexpr float kCostTraverse = 1.0f;
+constexpr float kCostIntersect = 1.0f;
+
+int levels_needed(size_t n) {  // inner-record levels a median-split subtree of n prims needs
+    int l = 0;
+    while (n > (size_t)kMaxLeafSize) { n = (n + 1) / 2; ++l; }
+    return l;
+}
+
+struct Builder {
+    const std::vector<InputTriangle>& in;
+    std::vector<Ref> refs;
+    Result& out;
+    float root_area = 1.f;
+
+    Builder(const std::vector<InputTriangle>& t, Result& r) : in(t), out(r) {}
+
+    int make_leaf(size_t begin, size_t end, const Box& box) {
+        const uint32_t first = (uint32_t)out.prim_index.size();
+        const uint32_t count = (uint32_t)(end - begin);
+        for (size_t i = begin; i < end; ++i) {
+            const InputTriangle& t = in[refs[i].idx];
+            float rec[12];
+            for (int a = 0; a < 3; ++a) {
+                rec[a] = t.v0[a];
+                rec[4 + a] = t.v1[a] - t.v0[a];  // same subtraction RayTriangle does (collision.h:35-36)
+                rec[8 + a] = t.v2[a] - t.v0[a];
+            }
+            memcpy(&rec[3], &t.packed_id, 4);
+            rec[7] = 0.f;
+            rec[11] = 0.f;
+            out.tris.insert(out.tris.end(), rec, rec + 12);
+            out.prim_index.push_back(refs[i].idx);
+        }
+        out.max_leaf = std::max(out.max_leaf, count);
+        out.sah_cost += (double)box.half_area() / root_area * count * kCostIntersect;
+        return ~(int)((first << 4) | count);
+    }
+
+    // returns child link; box = bounds of [begin,end)
+    int build(size_t begin, size_t end, const Box& box, int depth /* depth of the record this range would become */) {
+        const size_t n = end - begin;
+        Box cb;
+        for (size_t i = begin; i < end; ++i) cb.grow(refs[i].c);
+
+        // --- find the best binned SAH split over the three axes
+        float best_cost = FLT_MAX;
+        int best_axis = -1, best_bin = -1;
+        if (n > 1) {
+            for (int axis = 0; axis < 3; ++axis) {
+                const float lo = cb.mn[axis], ext = cb.mx[axis] - cb.mn[axis];
+                if (!(ext > 0.f)) continue;
+                Box bb[kSahBins];
+                uint32_t cnt[kSahBins] = {0};
+                const float scale = kSahBins / ext;
+                for (size_t i = begin; i < end; ++i) {
+                    int b = std::min(kSahBins - 1, std::max(0, (int)((refs[i].c[axis] - lo) * scale)));
+                    bb[b].grow(refs[i].box);
+                    ++cnt[b];
+                }
+                float right_area[kSahBins];
+                uint32_t right_cnt[kSahBins];
+                Box acc;
+                uint32_t c = 0;
+                for (int b = kSahBins - 1; b > 0; --b) {
+                    acc.grow(bb[b]);
+                    c += cnt[b];
+                    right_area[b] = acc.half_area();
+                    right_cnt[b] = c;
+                }
+                Box lacc;
+                uint32_t lc = 0;
+                for (int b = 0; b < kSahBins - 1; ++b) {
+                    lacc.grow(bb[b]);
+                    lc += cnt[b];
+                    if (lc == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = lacc.half_area() * lc + right_area[b + 1] * right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+        }
+        const float parent_area = std::max(box.half_area(), 1e-30f);
+        const float split_cost = kCostTraverse + kCostIntersect * best_cost / parent_area;
+        const float leaf_cost = kCostIntersect * (float)n;
+        if (n <= (size_t)kMaxLeafSize && (best_axis < 0 || leaf_cost <= split_cost || n == 1 || depth > kMaxDepth)) return make_leaf(begin, end, box);
+
+        // --- partition
+        size_t mid = begin;
+        bool median = (best_axis < 0);
+        if (!median) {
+            const float lo = cb.mn[best_axis], scale = kSahBins / (cb.mx[best_axis] - cb.mn[best_axis]);
+            auto it = std::partition(refs.begin() + begin, refs.begin() + end, [&](const Ref& r) {
+                int b = std::min(kSahBins - 1, std::max(0, (int)((r.c[best_axis] - lo) * scale)));
+                return b <= best_bin;
+            });
+            mid = (size_t)(it - refs.begin());
+            if (mid == begin || mid == end) median = true;
+            // depth guard: fall back to a median split if the SAH split could not be finished within kMaxDepth
+            else if (depth + std::max(levels_needed(mid - begin), levels_needed(end - mid)) > kMaxDepth) median = true;
+        }
+        if (median) {
+            int axis = 0;
+            float e = -1.f;
+            for (int a = 0; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > e) { e = cb.mx[a] - cb.mn[a]; axis = a; }
+            mid = begin + n / 2;
+            std::nth_element(refs.begin() + begin, refs.begin() + mid, refs.begin() + end,
+                             [axis](const Ref& a, const Ref& b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.idx < b.idx); });
+        }
+
+        Box lb, rb;
+        for (size_t i = begin; i < mid; ++i) lb.grow(refs[i].box);
+        for (size_t i = mid; i < end; ++i) rb.grow(refs[i].box);
+
+        const int me = (int)(out.nodes.size() / 16);
+        out.nodes.resize(out.nodes.size() + 16, 0.f);
+        out.max_depth = std::max(out.max_depth, (uint32_t)depth);
+        out.sah_cost += (double)box.half_area() / root_area * kCostTraverse;
+        const int c0 = build(begin, mid, lb, depth + 1);
+        const int c1 = build(mid, end, rb, depth + 1);
+        write_record(me, lb, rb, c0, c1);
+        return me;
+    }
+
+    static void pad(Box& b) {
+        // conservative inflation: the slab test and Moller-Trumbore round differently
+        for (int a = 0; a < 3; ++a) {
+            float m = std::max(std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a])), b.mx[a] - b.mn[a]);
+            float d = 1e-5f * m + 1e-7f;
+            b.mn[a] -= d;
+            b.mx[a] += d;
+        }
+    }
+
+    void write_record(int me, Box lb, Box rb, int c0, int c1) {
+        pad(lb);
+        pad(rb);
+        float* r = &out.nodes[(size_t)me * 16];
+        r[0] = lb.mn[0]; r[1] = lb.mx[0]; r[2] = lb.mn[1]; r[3] = lb.mx[1];
+        r[4] = rb.mn[0]; r[5] = rb.mx[0]; r[6] = rb.mn[1]; r[7] = rb.mx[1];
+        r[8] = lb.mn[2]; r[9] = lb.mx[2]; r[10] = rb.mn[2]; r[11] = rb.mx[2];
+        memcpy(&r[12], &c0, 4);
+        memcpy(&r[13], &c1, 4);
+        r[14] = 0.f;
+        r[15] = 0.f;
+    }
+
+    void run() {
+        refs.resize(in.size());
+        Box all;
+        for (size_t i = 0; i < in.size(); ++i) {
+            Ref& r = refs[i];
+            r.idx = (uint32_t)i;
+            r.box.grow(in[i].v0);
+            r.box.grow(in[i].v1);
+            r.box.grow(in[i].v2);
+            for (int a = 0; a < 3; ++a) r.c[a] = 0.5f * (r.box.mn[a] + r.box.mx[a]);
+            all.grow(r.box);
+        }
+        root_area = std::max(all.half_area(), 1e-30f);
+        out.nodes.clear();
+        out.tris.clear();
+        out.prim_index.clear();
+        out.tris.reserve(in.size() * 12);
+        out.prim_index.reserve(in.size());
+        const int empty_leaf = ~0;  // first 0, count 0
+        if (in.empty()) {
+            out.nodes.resize(16, 0.f);
+            write_record(0, Box{}, Box{}, empty_leaf, empty_leaf);
+            return;
+        }
+        int root = build(0, in.size(), all, 1);
+        if (root < 0) {
+            // the whole scene fits one leaf: wrap it in a root record (traversal always starts at record 0)
+            out.nodes.resize(16, 0.f);
+            Box none;
+            none.mn[0] = none.mn[1] = none.mn[2] = 0.f;
+            none.mx[0] = none.mx[1] = none.mx[2] = 0.f;
+            write_record(0, all, none, root, empty_leaf);
+            out.max_depth = 1;
+        }
+    }
+};
+
+}  // namespace
+
+void build(const std::vector<InputTriangle>& tris, Result& out) {
+    out = Result{};
+    Builder b(tris, out);
+    b.run();
+}
+
+}  // namespace bvh

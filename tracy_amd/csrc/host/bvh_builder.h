@@ -1,0 +1,42 @@
+// bvh_builder.h -- host-side build of the hip module's own acceleration structure.
+//
+// The reference's CPU module builds a median-split kd-tree with duplicated triangles
+// (src/kdtree.h:160-282) and its CUDA module uses no acceleration structure at all
+// (cuda_trace.cu:22-46). This module replaces both with one flat, world-space BVH2 built with
+// binned SAH and laid out for CDNA4: one 64-byte record per inner node that carries BOTH
+// child boxes (a lane fetches one cache line per traversal step and tests two boxes), leaves
+// encoded in the child links, triangles re-ordered into leaf order as 48-byte Moller-Trumbore
+// records (v0, e1, e2 + packed reference id).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace bvh {
+
+constexpr int kMaxDepth = 32;     // == traversal stack entries per lane (LDS)
+constexpr int kMaxLeafSize = 8;   // leaf count is packed in 4 bits
+constexpr int kSahBins = 16;
+
+struct InputTriangle {
+    float v0[3], v1[3], v2[3];
+    uint32_t packed_id;  // (mesh << 24) | triangle, as cpu_details.h:34
+};
+
+// 64-byte inner-node record (16 floats):
+//   [0..3]   c0.min.x c0.max.x c0.min.y c0.max.y
+//   [4..7]   c1.min.x c1.max.x c1.min.y c1.max.y
+//   [8..11]  c0.min.z c0.max.z c1.min.z c1.max.z
+//   [12..15] child0 child1 (int bits) 0 0
+// child >= 0: index of an inner-node record; child < 0: leaf, ~child = (first_prim << 4) | count
+struct Result {
+    std::vector<float> nodes;          // 16 floats per inner node, node 0 is the root
+    std::vector<float> tris;           // 12 floats per primitive in leaf order: v0.xyz id | e1.xyz 0 | e2.xyz 0
+    std::vector<uint32_t> prim_index;  // leaf-order position -> index into the input triangle array
+    uint32_t max_depth = 0;
+    uint32_t max_leaf = 0;
+    double sah_cost = 0.0;
+};
+
+void build(const std::vector<InputTriangle>& tris, Result& out);
+
+}  // namespace bvh

@@ -1,0 +1,150 @@
+"""HipTrace: the Python mirror of the `-kernel hip` render module.
+
+Same life cycle, method names and argument meaning as the reference's TracyModule
+(src/module.h:17-54) and its CPU implementation CpuTrace (cpu_trace.cpp:22-82); every method
+is a thin call into the C ABI of include/tracy_hip.h. The C++ twin a Tracy maintainer would
+compile into the application is csrc/host/hip_trace.h.
+
+There is no fallback path: if libtracy_hip.so or a HIP device is missing, Startup raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+DEFAULT_SEED = 0xABCDEF  # initrand(), src/random.h:66-69
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class HipTrace:
+    # TracyEvent (src/module.h:12)
+    eCreate, eResize, eCameraCut, eDestroy = range(4)
+
+    def __init__(self, device=0, pipeline=None, spp_per_update=1, seed=DEFAULT_SEED):
+        self._lib = None
+        self._ctx = C.c_void_p()
+        self.device = device
+        self.pipeline = pipeline
+        self.spp_per_update = spp_per_update
+        self.seed = seed
+        self._next_sample = 0
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc:
+            raise HipError(f"trh error {rc}: {self._lib.trh_last_error().decode()}")
+
+    # -- TracyModule interface ----------------------------------------------------------
+    def GetModuleName(self):
+        return "HIP Raytracing [MI355X gfx950]"
+
+    def Startup(self, scene, window=None):
+        """bool Startup(const WindowHandle, const Scene&) (src/module.h:35)."""
+        self._lib = capi.hip_lib()
+        self._check(self._lib.trh_init(self.device, C.byref(self._ctx)))
+        self._check(self._lib.trh_scene_upload(self._ctx, C.byref(scene.desc)))
+        if self.pipeline is not None:
+            self._check(self._lib.trh_set_pipeline(self._ctx, int(self.pipeline)))
+        self.width, self.height = scene.width, scene.height
+        self._upload_camera(scene)
+        self._next_sample = 0
+        return True
+
+    def Shutdown(self):
+        if self._lib is not None and self._ctx:
+            self._lib.trh_shutdown(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def OnUpdate(self, scene=None, dt=0.0):
+        """One progressive pass: spp_per_update new samples for every pixel
+        (CpuTrace::OnUpdate, cpu_trace.cpp:33-70, traces exactly one)."""
+        self.render(self._next_sample, self.spp_per_update)
+        self._next_sample += self.spp_per_update
+
+    def OnEvent(self, event, scene=None, window=None):
+        if event == self.eCameraCut:  # cpu_trace.cpp:76-78
+            if scene is not None:
+                self._upload_camera(scene)
+            self._check(self._lib.trh_reset_accumulation(self._ctx))
+            self._next_sample = 0
+
+    def OnRender(self, window=None):
+        """Returns the current linear mean image, (H, W, 4) float32, row 0 = bottom row."""
+        return self.resolve()[0]
+
+    def GetRayCount(self, reset=False):
+        return self.stats(reset)["rays"]
+
+    # -- direct C-ABI access used by tests and bench --------------------------------------
+    def _upload_camera(self, scene):
+        eye, ivp = scene.eye_ivp()
+        self.set_camera(eye, ivp)
+
+    def set_camera(self, eye, ivp):
+        eye = np.ascontiguousarray(eye, dtype=np.float32)
+        ivp = np.ascontiguousarray(ivp, dtype=np.float32)
+        self._check(self._lib.trh_set_camera(self._ctx, eye.ctypes.data_as(C.POINTER(C.c_float)), ivp.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def set_pipeline(self, pipeline):
+        self._check(self._lib.trh_set_pipeline(self._ctx, int(pipeline)))
+
+    def reset(self):
+        self._check(self._lib.trh_reset_accumulation(self._ctx))
+        self._next_sample = 0
+
+    def render(self, spp_begin, spp_count, seed=None, stats=False):
+        fn = self._lib.trh_render_stats if stats else self._lib.trh_render
+        self._check(fn(self._ctx, spp_begin, spp_count, self.seed if seed is None else seed))
+
+    def synchronize(self):
+        self._check(self._lib.trh_synchronize(self._ctx))
+
+    def accum_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.trh_accum_device_ptr(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bind_accum_buffer(self, dptr, nbytes):
+        """Accumulate into caller-owned device memory (e.g. a torch tensor's data_ptr())."""
+        self._check(self._lib.trh_bind_accum_buffer(self._ctx, dptr, nbytes))
+
+    def resolve(self, to_host=True):
+        n = C.c_uint64()
+        if to_host:
+            img = np.empty((self.height, self.width, 4), dtype=np.float32)
+            self._check(self._lib.trh_resolve(self._ctx, img.ctypes.data_as(C.c_void_p), C.byref(n)))
+            return img, n.value
+        self._check(self._lib.trh_resolve(self._ctx, None, C.byref(n)))
+        return None, n.value
+
+    def primary_hits(self):
+        ids = np.empty((self.height, self.width), dtype=np.uint32)
+        t = np.empty((self.height, self.width), dtype=np.float32)
+        uv = np.empty((self.height, self.width, 2), dtype=np.float32)
+        self._check(self._lib.trh_primary_hits(self._ctx, ids.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p)))
+        return ids, t, uv
+
+    def sample_radiance(self, sample_index, seed=None):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._lib.trh_sample_radiance(self._ctx, sample_index, self.seed if seed is None else seed, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def stats(self, reset=False):
+        s = capi.trh_stats()
+        self._check(self._lib.trh_get_stats(self._ctx, C.byref(s), int(reset)))
+        return {k: getattr(s, k) for k, _ in capi.trh_stats._fields_}
+
+    def bvh_info(self):
+        b = capi.trh_bvh_info()
+        self._check(self._lib.trh_get_bvh_info(self._ctx, C.byref(b)))
+        return {k: getattr(b, k) for k, _ in capi.trh_bvh_info._fields_}
+
+    def __del__(self):
+        try:
+            self.Shutdown()
+        except Exception:
+            pass
