@@ -1,0 +1,36 @@
+"""Summarises a tools/profile_bench.sh output directory: kernel stats + per-kernel PMC averages."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+print(f"# rocprofv3 summary ({os.path.basename(d)})\n")
+for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    print("## kernel-trace --stats\n")
+    print("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|")
+    for r in csv.DictReader(open(f)):
+        print(f"| {r['Name'][:70]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.3f} | {r['Percentage']} |")
+    print()
+agg = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("## PMC (average per dispatch; one rocprofv3 --pmc run per counter group)\n")
+out = {}
+for k, cs in agg.items():
+    if "megakernel" not in k and "k_extend" not in k and "k_shade" not in k and "k_generate" not in k:
+        continue
+    print(f"### {k[:90]}\n")
+    print("| counter | avg per dispatch | dispatches |\n|---|---|---|")
+    out[k] = {}
+    for c, v in sorted(cs.items()):
+        # the first dispatches are the instrumented pass and the warm-up; keep them out of the average when possible
+        vv = v[2:] if len(v) > 3 else v
+        a = sum(vv) / len(vv)
+        out[k][c] = a
+        print(f"| {c} | {a:.6g} | {len(vv)} |")
+    print()
+json.dump(out, open(os.path.join(d, "pmc_avg.json"), "w"), indent=1)

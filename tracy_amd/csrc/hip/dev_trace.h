@@ -89,6 +89,35 @@ DEVFN void camera_ray(const DevScene& sc, float s, float t, V3& o, V3& d) {
     d = normalize(mk(p[0] / p[3], p[1] / p[3], p[2] / p[3]) - o);
 }
 
+// ------------------------------------------------------------------ candidate acceptance
+// Reference rule (collision.h:66): reject t < EPS || t > RayT, so an equal t REPLACES the stored
+// hit: the last-tested triangle wins. The reference tests meshes in mesh-id order (one TLAS leaf
+// for <= 16 objects, cpu_details.cpp:128-142) and, before it looks at a later mesh, prunes it with
+// RayAABB(mesh AABB, minT) whose second clause is the STRICT tmin < minT (collision.h:130).
+// This BVH visits triangles in no particular order, so:
+//   * same mesh, exact tie            -> the larger triangle id wins (documented approximation);
+//   * different meshes, |dt| <= 1e-5 t -> replay the reference's pairwise decision: the later mesh b
+//     beats the earlier mesh a iff t_b <= t_a and slab_tmin(AABB_b) < t_a. This is what decides
+//     coincident coplanar faces of two objects (data/scenes/random.scn: light box on a wall).
+DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 inv, float t, uint32_t id, const Hit& hit) {
+    if (t < EPS) return false;
+    const uint32_t mc = id >> 24, mh = hit.id >> 24;
+    if (mc == mh || !(fabsf(t - hit.t) <= 1e-5f * hit.t)) return t < hit.t || (t == hit.t && id > hit.id);
+    const bool c_later = mc > mh;
+    const float t_a = c_later ? hit.t : t;
+    const float t_b = c_later ? t : hit.t;
+    const uint32_t mb = c_later ? mc : mh;
+    const float4 bmn = sc.mesh_aabb[mb * 2 + 0], bmx = sc.mesh_aabb[mb * 2 + 1];
+    const float x0 = (bmn.x - o.x) * inv.x, x1 = (bmx.x - o.x) * inv.x;
+    const float y0 = (bmn.y - o.y) * inv.y, y1 = (bmx.y - o.y) * inv.y;
+    const float z0 = (bmn.z - o.z) * inv.z, z1 = (bmx.z - o.z) * inv.z;
+    const float tx = (x1 < x0) ? x1 : x0, ty = (y1 < y0) ? y1 : y0, tz = (z1 < z0) ? z1 : z0;   // glm::min
+    const float tyz = (ty < tz) ? tz : ty;                                                       // glm::max
+    const float tmin_b = (tx < tyz) ? tyz : tx;
+    const bool b_wins = (t_b <= t_a) && (tmin_b < t_a);
+    return c_later ? b_wins : !b_wins;
+}
+
 // ------------------------------------------------------------------ nearest hit
 // stack: this lane's LDS column, entry i at stack[i * TRH_BLOCK]
 template <bool STATS>
@@ -98,6 +127,8 @@ DEVFN void intersect(const DevScene& sc, V3 o, V3 d, Hit& hit, int* __restrict__
     hit.u = hit.v = 0.f;
     hit.prim = -1;
     hit.id = TRH_MISS_ID;
+    if (d.x != d.x) return;  // NaN direction (normalize(0) after total internal reflection, material.h:242-263):
+                             // every RayAABB comparison is false in the reference, i.e. a miss
     int sp = 0;
     int node = 0;
     for (;;) {
@@ -155,9 +186,7 @@ DEVFN void intersect(const DevScene& sc, V3 o, V3 d, Hit& hit, int* __restrict__
             if (ok) {
                 const float rdet = 1.f / det;
                 const float t = dot_f(e2, qvec) * rdet;
-                // reference: reject t < EPS || t > RayT; an equal t replaces (last tested wins). Without the
-                // reference's test order, exact ties go to the larger packed id (documented in DESIGN.md).
-                if (!(t < EPS) && (t < hit.t || (t == hit.t && id > hit.id))) {
+                if (accept_candidate(sc, o, inv, t, id, hit)) {
                     hit.t = t;
                     hit.u = u * rdet;
                     hit.v = v * rdet;

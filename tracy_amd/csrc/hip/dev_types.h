@@ -33,6 +33,7 @@ struct DevScene {
     const float4* tris;        // 3 float4 per primitive, leaf order: (v0, id) (e1, 0) (e2, 0)
     const float4* shade;       // 4 float4 per primitive: n0 n1 n2 (9) uv0 uv1 uv2 (6) material (1)
     const float4* tangents;    // 3 float4 per primitive (t0 t1 t2), NULL if no normal map is used
+    const float4* mesh_aabb;   // 2 float4 per mesh: the reference's Mesh::GetAABB (min, max), unpadded
     const DevMaterial* materials;
     const DevTexture* textures;
     int32_t width, height;

@@ -412,6 +412,13 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
         if ((rc = dev_alloc_copy(c, tang.data(), tang.size(), &dp))) return rc;
         sc.tangents = (const float4*)dp;
     }
+    std::vector<float> maabb((size_t)d->mesh_count * 8, 0.f);
+    for (uint32_t m = 0; m < d->mesh_count; ++m) {
+        memcpy(&maabb[m * 8 + 0], d->meshes[m].aabb_min, 12);
+        memcpy(&maabb[m * 8 + 4], d->meshes[m].aabb_max, 12);
+    }
+    if ((rc = dev_alloc_copy(c, maabb.data(), maabb.size(), &dp))) return rc;
+    sc.mesh_aabb = (const float4*)dp;
     std::vector<DevMaterial> mats(d->material_count);
     for (uint32_t m = 0; m < d->material_count; ++m) {
         const trh_material& s = d->materials[m];
