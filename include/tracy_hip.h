@@ -97,8 +97,9 @@ typedef struct trh_scene_desc {
 
 /* Which kernel pipeline trh_render uses. Both produce the same per-sample paths. */
 typedef enum trh_pipeline {
-    TRH_PIPELINE_MEGAKERNEL = 0, /* one persistent kernel, lanes regenerate samples in place */
-    TRH_PIPELINE_WAVEFRONT = 1   /* generate / extend / shade queues, wave64 ballot compaction */
+    TRH_PIPELINE_MEGAKERNEL = 0, /* persistent waves, wave-local path scheduler (default) */
+    TRH_PIPELINE_WAVEFRONT = 1,  /* generate / extend / shade queues, wave64 ballot compaction */
+    TRH_PIPELINE_MEGAKERNEL_SIMPLE = 2  /* first-generation kernel (lane == pixel), kept for A/B */
 } trh_pipeline;
 
 typedef struct trh_context trh_context;   /* opaque; one per HIP device */
@@ -184,6 +185,12 @@ int trh_sample_radiance(trh_context* ctx, uint32_t sample_index, uint64_t seed, 
 /* Ray / sample counters. Replaces TracyModule::GetRayCount (src/module.h:53) with 64-bit
  * counters (the reference's u32 wraps at GPU rates). */
 int trh_get_stats(trh_context* ctx, trh_stats* out, int reset);
+
+/* Diagnostics of the instrumented kernel (trh_render_stats), since the last stats reset:
+ * out[0..4] = wave-level inner-node iterations, wave-level triangle-loop iterations, wave-level
+ * shade calls, wave-level generate calls, lane-level generate calls. Lane utilisation of a
+ * phase = lane-level count / (64 * wave-level count), e.g. (box_tests/2) / (64*out[0]). */
+int trh_get_debug_counters(trh_context* ctx, uint64_t* out, uint32_t n);
 
 /* Info about the uploaded acceleration structure (for DESIGN/bench reporting). */
 typedef struct trh_bvh_info {

@@ -1,0 +1,19 @@
+"""Development aid: per-phase lane utilisation from the instrumented kernel."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tracy_amd import Scene, HipTrace
+for scene in sys.argv[1:] or ["dragon"]:
+    sc = Scene(f"data/scenes/{scene}.scn", 1920, 1080)
+    for pipe in (0, 2):
+        mod = HipTrace(pipeline=pipe); mod.Startup(sc)
+        mod.stats(reset=True)
+        mod.render(0, 64, stats=True)
+        st = mod.stats(); d = mod.debug_counters()
+        u_inner = (st["box_tests"] / 2) / (64 * max(1, d["wave_inner_iters"]))
+        u_leaf = st["tri_tests"] / (64 * max(1, d["wave_leaf_iters"]))
+        u_shade = st["rays"] / (64 * max(1, d["wave_shade_calls"]))
+        u_gen = d["lanes_gen"] / (64 * max(1, d["wave_gen_calls"]))
+        print(scene, "pipeline", pipe, f"lane utilisation: inner {u_inner:.3f} leaf {u_leaf:.3f} shade {u_shade:.3f} gen {u_gen:.3f}",
+              f"| per ray: inner visits {st['box_tests']/2/st['rays']:.2f} tri {st['tri_tests']/st['rays']:.2f}",
+              f"| wave iters per ray*64: inner {d['wave_inner_iters']*64/st['rays']:.2f} leaf {d['wave_leaf_iters']*64/st['rays']:.2f} shade {d['wave_shade_calls']*64/st['rays']:.2f}")
+        mod.Shutdown()

@@ -16,6 +16,7 @@ TRH_VERTEX_FLOATS = 14
 TRH_FLAG_RUSSIAN_ROULETTE = 1
 TRH_PIPELINE_MEGAKERNEL = 0
 TRH_PIPELINE_WAVEFRONT = 1
+TRH_PIPELINE_MEGAKERNEL_SIMPLE = 2
 
 
 class trh_material(C.Structure):
@@ -97,6 +98,7 @@ HIP_SYMBOLS = {
     "trh_primary_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trh_sample_radiance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]),
     "trh_get_stats": (C.c_int, [C.c_void_p, C.POINTER(trh_stats), C.c_int]),
+    "trh_get_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32]),
     "trh_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(trh_bvh_info)]),
 }
 

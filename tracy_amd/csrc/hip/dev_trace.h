@@ -67,7 +67,15 @@ DEVFN uint32_t path_rng_state(uint32_t pixel_index, uint32_t sample_index, uint3
     return pcg_hash(pixel_index ^ pcg_hash(sample_index ^ seed_hash));
 }
 
-struct Counters { uint32_t rays, box_tests, tri_tests, hits, tex_fetches; };
+struct Counters {
+    uint32_t rays, box_tests, tri_tests, hits, tex_fetches;
+    uint32_t w_inner, w_leaf, w_shade, w_gen, l_gen;   // instrumented kernel only
+};
+// true for exactly one of the currently active lanes (wave-level event counting)
+DEVFN bool first_active_lane() {
+    const unsigned long long m = __ballot(true);
+    return (uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u);
+}
 
 struct Hit {
     float t, u, v;
@@ -119,86 +127,112 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 inv, float t, uint32_t 
 }
 
 // ------------------------------------------------------------------ nearest hit
-// stack: this lane's LDS column, entry i at stack[i * TRH_BLOCK]
+// Resumable stack traversal of the 64-byte BVH2 records. The state lives in registers (Trav) plus
+// this lane's LDS stack column (entry i at stack[i * TRH_BLOCK]); a kernel may run trav_inner /
+// trav_leaf for a while, do something else (shade other lanes, refill) and come back.
+struct Trav {
+    V3 inv;      // Ray ctor: rcp(direction) (src/ray.h:18)
+    int node;    // >= 0: inner-node record; < 0: leaf link ~((first << 4) | count)
+    int sp;      // stack entries in use; < 0 <=> traversal finished
+    Hit hit;
+};
+DEVFN bool trav_active(const Trav& tv) { return tv.sp >= 0; }
+
+DEVFN void trav_begin(Trav& tv, V3 d) {
+    tv.inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    tv.hit.t = 3.402823466e+38f;  // HitData.t = FLT_MAX (cpu_trace.cpp:119)
+    tv.hit.u = tv.hit.v = 0.f;
+    tv.hit.prim = -1;
+    tv.hit.id = TRH_MISS_ID;
+    // NaN direction (normalize(0) after total internal reflection, material.h:242-263): every RayAABB
+    // comparison is false in the reference, i.e. a miss
+    const bool nan = d.x != d.x;
+    tv.sp = nan ? -1 : 0;
+    tv.node = nan ? ~0 : 0;
+}
+
+DEVFN void trav_pop(Trav& tv, const int* __restrict__ stack) {
+    --tv.sp;
+    const int top = stack[(tv.sp < 0 ? 0 : tv.sp) * TRH_BLOCK];
+    tv.node = tv.sp < 0 ? ~0 : top;   // ~0 = empty leaf: nothing left to do
+}
+
+// one inner-node record: one 64-byte fetch, two slab tests. Precondition: tv.node >= 0.
+template <bool STATS>
+DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stack, Counters& cnt) {
+    const float4 n0 = sc.nodes[tv.node * 4 + 0];
+    const float4 n1 = sc.nodes[tv.node * 4 + 1];
+    const float4 nz = sc.nodes[tv.node * 4 + 2];
+    const float4 lk = sc.nodes[tv.node * 4 + 3];
+    if (STATS) { cnt.box_tests += 2; if (first_active_lane()) cnt.w_inner += 1; }
+    const V3 inv = tv.inv;
+    const float ax0 = (n0.x - o.x) * inv.x, ax1 = (n0.y - o.x) * inv.x;
+    const float ay0 = (n0.z - o.y) * inv.y, ay1 = (n0.w - o.y) * inv.y;
+    const float az0 = (nz.x - o.z) * inv.z, az1 = (nz.y - o.z) * inv.z;
+    const float bx0 = (n1.x - o.x) * inv.x, bx1 = (n1.y - o.x) * inv.x;
+    const float by0 = (n1.z - o.y) * inv.y, by1 = (n1.w - o.y) * inv.y;
+    const float bz0 = (nz.z - o.z) * inv.z, bz1 = (nz.w - o.z) * inv.z;
+    const float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.f));
+    const float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), tv.hit.t));
+    const float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.f));
+    const float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), tv.hit.t));
+    const bool h0 = tmin0 <= tmax0;
+    const bool h1 = tmin1 <= tmax1;
+    const int c0 = __float_as_int(lk.x), c1 = __float_as_int(lk.y);
+    const bool swp = h1 && (!h0 || tmin1 < tmin0);   // child 1 is the nearer (or the only) hit
+    const int nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
+    stack[tv.sp * TRH_BLOCK] = farc;   // unconditional: slot sp is free; it only counts if both were hit
+    tv.sp += (h0 && h1) ? 1 : 0;
+    if (h0 || h1) tv.node = nearc;
+    else trav_pop(tv, stack);
+}
+
+// one leaf: Moller-Trumbore over count 48-byte records (collision.h:33-74), then pop.
+// Precondition: tv.sp >= 0 && tv.node < 0.
+template <bool STATS>
+DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__ stack, Counters& cnt) {
+    const uint32_t bits = ~(uint32_t)tv.node;
+    const uint32_t first = bits >> 4, count = bits & 15u;
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t p = first + i;
+        const float4 r0 = sc.tris[p * 3 + 0];
+        const float4 r1 = sc.tris[p * 3 + 1];
+        const float4 r2 = sc.tris[p * 3 + 2];
+        if (STATS) { cnt.tri_tests += 1; if (first_active_lane()) cnt.w_leaf += 1; }
+        const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z);
+        const uint32_t id = __float_as_uint(r0.w);
+        const V3 pvec = cross_f(d, e2);
+        const V3 tvec = o - v0;
+        const float det = dot_f(e1, pvec);
+        const float u = dot_f(tvec, pvec);
+        const V3 qvec = cross_f(tvec, e1);
+        const float v = dot_f(d, qvec);
+        // collision.h:44,51,59 evaluated without short-circuit branches
+        const bool ok = !(det < EPS) & !(u < EPS) & !(u > det) & !(v < EPS) & !(u + v > det);
+        if (ok) {
+            const float rdet = 1.f / det;
+            const float t = dot_f(e2, qvec) * rdet;
+            if (accept_candidate(sc, o, tv.inv, t, id, tv.hit)) {
+                tv.hit.t = t;
+                tv.hit.u = u * rdet;
+                tv.hit.v = v * rdet;
+                tv.hit.prim = (int)p;
+                tv.hit.id = id;
+            }
+        }
+    }
+    trav_pop(tv, stack);
+}
+
 template <bool STATS>
 DEVFN void intersect(const DevScene& sc, V3 o, V3 d, Hit& hit, int* __restrict__ stack, Counters& cnt) {
-    const V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // Ray ctor: rcp(direction)
-    hit.t = 3.402823466e+38f;  // HitData.t = FLT_MAX (cpu_trace.cpp:119)
-    hit.u = hit.v = 0.f;
-    hit.prim = -1;
-    hit.id = TRH_MISS_ID;
-    if (d.x != d.x) return;  // NaN direction (normalize(0) after total internal reflection, material.h:242-263):
-                             // every RayAABB comparison is false in the reference, i.e. a miss
-    int sp = 0;
-    int node = 0;
-    for (;;) {
-        // ---- inner records: one 64-byte fetch, two slab tests
-        while (node >= 0) {
-            const float4 n0 = sc.nodes[node * 4 + 0];
-            const float4 n1 = sc.nodes[node * 4 + 1];
-            const float4 nz = sc.nodes[node * 4 + 2];
-            const float4 lk = sc.nodes[node * 4 + 3];
-            if (STATS) cnt.box_tests += 2;
-            const float ax0 = (n0.x - o.x) * inv.x, ax1 = (n0.y - o.x) * inv.x;
-            const float ay0 = (n0.z - o.y) * inv.y, ay1 = (n0.w - o.y) * inv.y;
-            const float az0 = (nz.x - o.z) * inv.z, az1 = (nz.y - o.z) * inv.z;
-            const float bx0 = (n1.x - o.x) * inv.x, bx1 = (n1.y - o.x) * inv.x;
-            const float by0 = (n1.z - o.y) * inv.y, by1 = (n1.w - o.y) * inv.y;
-            const float bz0 = (nz.z - o.z) * inv.z, bz1 = (nz.w - o.z) * inv.z;
-            const float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.f));
-            const float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), hit.t));
-            const float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.f));
-            const float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), hit.t));
-            const bool h0 = tmin0 <= tmax0;
-            const bool h1 = tmin1 <= tmax1;
-            const int c0 = __float_as_int(lk.x), c1 = __float_as_int(lk.y);
-            if (h0 && h1) {
-                const bool swp = tmin1 < tmin0;
-                node = swp ? c1 : c0;
-                stack[sp * TRH_BLOCK] = swp ? c0 : c1;
-                ++sp;
-            } else if (h0 || h1) {
-                node = h0 ? c0 : c1;
-            } else {
-                if (sp == 0) return;
-                --sp;
-                node = stack[sp * TRH_BLOCK];
-            }
-        }
-        // ---- leaf: Moller-Trumbore over count 48-byte records (collision.h:33-74)
-        const uint32_t bits = ~(uint32_t)node;
-        const uint32_t first = bits >> 4, count = bits & 15u;
-        for (uint32_t i = 0; i < count; ++i) {
-            const uint32_t p = first + i;
-            const float4 r0 = sc.tris[p * 3 + 0];
-            const float4 r1 = sc.tris[p * 3 + 1];
-            const float4 r2 = sc.tris[p * 3 + 2];
-            if (STATS) cnt.tri_tests += 1;
-            const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z);
-            const uint32_t id = __float_as_uint(r0.w);
-            const V3 pvec = cross_f(d, e2);
-            const V3 tvec = o - v0;
-            const float det = dot_f(e1, pvec);
-            const float u = dot_f(tvec, pvec);
-            const V3 qvec = cross_f(tvec, e1);
-            const float v = dot_f(d, qvec);
-            bool ok = !(det < EPS) && !(u < EPS || u > det) && !(v < EPS || u + v > det);
-            if (ok) {
-                const float rdet = 1.f / det;
-                const float t = dot_f(e2, qvec) * rdet;
-                if (accept_candidate(sc, o, inv, t, id, hit)) {
-                    hit.t = t;
-                    hit.u = u * rdet;
-                    hit.v = v * rdet;
-                    hit.prim = (int)p;
-                    hit.id = id;
-                }
-            }
-        }
-        if (sp == 0) return;
-        --sp;
-        node = stack[sp * TRH_BLOCK];
+    Trav tv;
+    trav_begin(tv, d);
+    while (trav_active(tv)) {
+        while (tv.node >= 0) trav_inner<STATS>(sc, o, tv, stack, cnt);
+        if (trav_active(tv)) trav_leaf<STATS>(sc, o, d, tv, stack, cnt);
     }
+    hit = tv.hit;
 }
 
 // ------------------------------------------------------------------ textures (src/texture.h:50-57)
@@ -236,6 +270,7 @@ struct PathState {
 template <bool STATS>
 DEVFN bool shade(const DevScene& sc, PathState& ps, const Hit& hit, Counters& cnt) {
     cnt.rays += 1;  // ++raycount_ (cpu_trace.cpp:115-116)
+    if (STATS) { if (first_active_lane()) cnt.w_shade += 1; }
     ps.bounce += 1;
     if (hit.prim >= 0) {
         if (STATS) cnt.hits += 1;

@@ -46,11 +46,17 @@ struct DevScene {
 struct RenderParams {
     uint32_t spp_begin;
     uint32_t spp_count;
-    uint32_t seed32;
+    uint32_t seed32;          // pcg_hash of the folded 64-bit seed
     uint32_t tiles_x, tiles_y;
+    uint32_t tile_w_log2, tile_h_log2;   // wave tile = (1 << tile_w_log2) x (1 << tile_h_log2) pixels
+    uint32_t stack_entries;   // LDS stack entries per lane (>= BVH depth)
+    uint32_t refill_thresh;   // lanes waiting for shade/refill that end a traversal phase
 };
 
 // device-side counters, one cache line
 struct DevCounters {
-    unsigned long long rays, samples, box_tests, tri_tests, hits, tex_fetches, pad0, pad1;
+    unsigned long long rays, samples, box_tests, tri_tests, hits, tex_fetches;
+    // wave-level iteration counts (instrumented kernel only): lane utilisation per phase =
+    // lane-level count / (64 * wave-level count)
+    unsigned long long wave_inner_iters, wave_leaf_iters, wave_shade_calls, wave_gen_calls, lanes_gen, pad[5];
 };

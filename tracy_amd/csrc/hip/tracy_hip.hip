@@ -13,8 +13,10 @@
 #include "../host/bvh_builder.h"
 #include "dev_trace.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,17 +47,31 @@ DEVFN void flush_counters(const Counters& c, DevCounters* g) {
             atomicAdd(&g->tex_fetches, (unsigned long long)tf);
         }
     }
+    if (STATS) {
+        const uint32_t a = wave_sum(c.w_inner), b = wave_sum(c.w_leaf), d = wave_sum(c.w_shade), e = wave_sum(c.w_gen), f = wave_sum(c.l_gen);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g->wave_inner_iters, (unsigned long long)a);
+            atomicAdd(&g->wave_leaf_iters, (unsigned long long)b);
+            atomicAdd(&g->wave_shade_calls, (unsigned long long)d);
+            atomicAdd(&g->wave_gen_calls, (unsigned long long)e);
+            atomicAdd(&g->lanes_gen, (unsigned long long)f);
+        }
+    }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_megakernel_simple: first-generation kernel, kept for A/B measurements (TRH_PIPELINE_MEGAKERNEL_SIMPLE).
+// One lane owns one pixel and loops over its samples; a wave waits for its slowest lane every bounce.
+// ---------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
-                                                          DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
+__global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, RenderParams rp, float4* __restrict__ accum,
+                                                                 DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
     __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
     int* stack = &s_stack[threadIdx.x];
     const int lane = threadIdx.x & 63;
     const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
     const uint32_t seed_hash = rp.seed32;
-    Counters cnt = {0, 0, 0, 0, 0};
+    Counters cnt = {};
 
     for (;;) {
         uint32_t tile = 0;
@@ -99,6 +115,127 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderPar
     flush_counters<STATS>(cnt, counters);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_megakernel: persistent waves with a wave-local path scheduler.
+//
+// A wave pulls a tile (P pixels x S samples = P*S camera paths, "items") from a global counter.
+// Lanes are NOT bound to pixels: whenever a lane's path ends it takes the next item of the tile
+// (ballot + mbcnt prefix, no memory traffic), so a tile that mixes sky pixels (1 ray per sample)
+// and dragon pixels (3-5 rays) keeps all 64 lanes busy until the tile's items run out.
+// Inside an item the lane alternates between a resumable BVH traversal (trav_inner/trav_leaf)
+// and shading. The wave stays in the traversal loop until `refill_thresh` lanes have finished
+// their ray (or nobody is traversing); only then it pays for the divergent shade + refill code,
+// with at least that many lanes active. Radiance is accumulated per pixel in LDS (ds_add_f32)
+// and flushed to the float4 accumulation buffer once per tile by plain stores: a tile is owned
+// by exactly one wave per launch, so no global atomics are needed.
+// LDS per workgroup: stack_entries x 256 ints (traversal stacks, one bank-conflict-free column
+// per lane) + 4 waves x P x 3 floats (tile accumulators).
+// ---------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
+                                                          DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
+    extern __shared__ int s_dyn[];
+    int* stack = s_dyn + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t P_log2 = rp.tile_w_log2 + rp.tile_h_log2;
+    const uint32_t P = 1u << P_log2;
+    float* wacc = reinterpret_cast<float*>(s_dyn + rp.stack_entries * TRH_BLOCK) + (threadIdx.x >> 6) * (P * 3);
+    const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
+    const uint32_t total = P * rp.spp_count;   // items per tile
+    Counters cnt = {};
+
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(tile_counter, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= ntiles) break;  // wave-uniform exit: every wave reaches it
+        const int tile_x0 = (int)((tile % rp.tiles_x) << rp.tile_w_log2);
+        const int tile_y0 = (int)((tile / rp.tiles_x) << rp.tile_h_log2);
+        for (uint32_t i = lane; i < P * 3; i += 64) wacc[i] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+
+        uint32_t next = 0;          // wave-uniform: next unassigned item of this tile
+        PathState ps;
+        ps.o = ps.d = ps.throughput = ps.radiance = mk(0.f, 0.f, 0.f);
+        ps.rng = 0;
+        ps.bounce = 0;
+        Trav tv;
+        tv.inv = mk(0.f, 0.f, 0.f);
+        tv.node = ~0;
+        tv.sp = -1;
+        tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
+        uint32_t pix = 0;           // pixel-in-tile of the item this lane works on
+        bool has_path = false;      // a traversal result is waiting to be shaded
+        bool exhausted = false;     // no items left for this lane
+
+        for (;;) {
+            // ---- shade the lanes whose ray is finished
+            if (has_path && !trav_active(tv)) {
+                const bool cont = shade<STATS>(sc, ps, tv.hit, cnt);
+                if (cont) {
+                    trav_begin(tv, ps.d);
+                } else {
+                    __hip_atomic_fetch_add(&wacc[pix * 3 + 0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&wacc[pix * 3 + 1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&wacc[pix * 3 + 2], ps.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    has_path = false;
+                }
+            }
+            // ---- refill: idle lanes take the next items of the tile, in lane order
+            const bool want = !has_path && !exhausted;
+            const unsigned long long wmask = __ballot(want);
+            if (wmask != 0ull) {
+                if (want) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
+                    const uint32_t item = next + rank;
+                    if (item < total) {
+                        pix = item & (P - 1u);
+                        const uint32_t sample = rp.spp_begin + (item >> P_log2);
+                        const int px = tile_x0 + (int)(pix & ((1u << rp.tile_w_log2) - 1u));
+                        const int py = tile_y0 + (int)(pix >> rp.tile_w_log2);
+                        if (px < sc.width && py < sc.height) {
+                            if (STATS) { cnt.l_gen += 1; if (first_active_lane()) cnt.w_gen += 1; }
+                            generate(sc, ps, px, py, sample, rp.seed32);
+                            trav_begin(tv, ps.d);
+                            has_path = true;
+                        }   // else: pixel outside the frame (partial edge tile): the item is dropped
+                    } else {
+                        exhausted = true;
+                    }
+                }
+                next += (uint32_t)__popcll(wmask);
+            }
+            // ---- traverse until enough lanes are waiting again
+            unsigned long long tmask = __ballot(trav_active(tv));
+            if (tmask == 0ull) {
+                if (__ballot(!exhausted) == 0ull) break;   // tile done
+                continue;                                  // dropped items / paths that ended at once
+            }
+            for (;;) {
+                while (tv.node >= 0) trav_inner<STATS>(sc, ps.o, tv, stack, cnt);
+                if (trav_active(tv)) trav_leaf<STATS>(sc, ps.o, ps.d, tv, stack, cnt);
+                tmask = __ballot(trav_active(tv));
+                const unsigned long long waiting = __ballot(has_path && !trav_active(tv));
+                if (tmask == 0ull || (uint32_t)__popcll(waiting) >= rp.refill_thresh) break;
+            }
+        }
+        // ---- flush the tile: plain read-modify-write, the tile belongs to this wave
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < P; i += 64) {
+            const int px = tile_x0 + (int)(i & ((1u << rp.tile_w_log2) - 1u));
+            const int py = tile_y0 + (int)(i >> rp.tile_w_log2);
+            if (px < sc.width && py < sc.height) {
+                const size_t p = (size_t)py * sc.width + px;
+                float4 a = accum[p];
+                a.x += wacc[i * 3 + 0]; a.y += wacc[i * 3 + 1]; a.z += wacc[i * 3 + 2]; a.w += (float)rp.spp_count;
+                accum[p] = a;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    flush_counters<STATS>(cnt, counters);
+}
+
 __global__ __launch_bounds__(TRH_BLOCK) void k_primary_hits(DevScene sc, uint32_t* __restrict__ ids, float* __restrict__ t_out, float2* __restrict__ uv_out) {
     __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
     int* stack = &s_stack[threadIdx.x];
@@ -110,7 +247,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_primary_hits(DevScene sc, uint32_
     V3 o, d;
     camera_ray(sc, u, v, o, d);
     Hit hit;
-    Counters cnt = {0, 0, 0, 0, 0};
+    Counters cnt = {};
     intersect<false>(sc, o, d, hit, stack, cnt);
     ids[p] = hit.id;
     t_out[p] = hit.t;
@@ -125,7 +262,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_sample_radiance(DevScene sc, uint
     const int px = (int)(p % (uint32_t)sc.width), py = (int)(p / (uint32_t)sc.width);
     PathState ps;
     generate(sc, ps, px, py, sample, seed_hash);
-    Counters cnt = {0, 0, 0, 0, 0};
+    Counters cnt = {};
     bool alive = true;
     while (alive) {
         Hit hit;
@@ -194,7 +331,8 @@ struct trh_context {
     double kernel_ms = 0.0;
     uint64_t launches = 0;
     trh_bvh_info bvh{};
-    int mega_grid = 0, mega_grid_stats = 0;
+    int simple_grid = 0, simple_grid_stats = 0;
+    uint32_t refill_thresh = 16;
 };
 
 namespace {
@@ -235,16 +373,41 @@ int collect_timings(trh_context* c) {
 }
 
 template <bool STATS>
-int launch_megakernel(trh_context* c, const RenderParams& rp) {
-    int& grid = STATS ? c->mega_grid_stats : c->mega_grid;
+int launch_megakernel_simple(trh_context* c, RenderParams rp) {
+    int& grid = STATS ? c->simple_grid_stats : c->simple_grid;
     if (grid == 0) {
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS>, TRH_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel_simple<STATS>, TRH_BLOCK, 0));
         if (per_cu < 1) per_cu = 1;
         grid = per_cu * c->num_cus;
     }
+    rp.tile_w_log2 = rp.tile_h_log2 = 3;
+    rp.tiles_x = (uint32_t)(c->sc.width + 7) / 8;
+    rp.tiles_y = (uint32_t)(c->sc.height + 7) / 8;
     HIP_TRY(hipMemsetAsync(c->tile_counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL(k_megakernel<STATS>, dim3(grid), dim3(TRH_BLOCK), 0, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
+    hipLaunchKernelGGL(k_megakernel_simple<STATS>, dim3(grid), dim3(TRH_BLOCK), 0, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
+    HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+template <bool STATS>
+int launch_megakernel(trh_context* c, RenderParams rp) {
+    // tile = 8x8 pixels x spp items; with few samples per call use 16x16 pixels so that a wave still
+    // has several items per lane to schedule
+    const uint32_t wl = rp.spp_count >= 8 ? 3u : 4u, hl = wl;
+    rp.tile_w_log2 = wl;
+    rp.tile_h_log2 = hl;
+    rp.tiles_x = ((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl;
+    rp.tiles_y = ((uint32_t)c->sc.height + (1u << hl) - 1u) >> hl;
+    rp.stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u);
+    rp.refill_thresh = c->refill_thresh;
+    const size_t lds = ((size_t)rp.stack_entries * TRH_BLOCK + (size_t)TRH_WAVES_PER_BLOCK * (3u << (wl + hl))) * 4;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS>, TRH_BLOCK, lds));
+    if (per_cu < 1) per_cu = 1;
+    const int grid = per_cu * c->num_cus;
+    HIP_TRY(hipMemsetAsync(c->tile_counter, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(k_megakernel<STATS>, dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
     HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
@@ -259,13 +422,13 @@ int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t
     rp.spp_begin = spp_begin;
     rp.spp_count = spp_count;
     rp.seed32 = seed_hash_of(seed);
-    rp.tiles_x = (uint32_t)(c->sc.width + 7) / 8;
-    rp.tiles_y = (uint32_t)(c->sc.height + 7) / 8;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
-    int rc = stats ? launch_megakernel<true>(c, rp) : launch_megakernel<false>(c, rp);
+    int rc;
+    if (c->pipeline == TRH_PIPELINE_MEGAKERNEL_SIMPLE) rc = stats ? launch_megakernel_simple<true>(c, rp) : launch_megakernel_simple<false>(c, rp);
+    else rc = stats ? launch_megakernel<true>(c, rp) : launch_megakernel<false>(c, rp);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->pending.emplace_back(e0, e1);
@@ -312,6 +475,10 @@ int trh_init(int device, trh_context** ctx_out) {
     if (hipMalloc(&p, 256) != hipSuccess) { delete c; return fail(TRH_ERR_HIP, "hipMalloc(tile counter) failed"); }
     c->tile_counter = (unsigned int*)p;
     (void)hipMemset(p, 0, 256);
+    if (const char* e = getenv("TRH_REFILL_THRESH")) {   // development knob
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) c->refill_thresh = (uint32_t)v;
+    }
     *ctx_out = c;
     return TRH_OK;
 }
@@ -499,7 +666,8 @@ int trh_reset_accumulation(trh_context* c) {
 
 int trh_set_pipeline(trh_context* c, int pipeline) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: ctx is NULL");
-    if (pipeline != TRH_PIPELINE_MEGAKERNEL) return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: unknown pipeline");
+    if (pipeline != TRH_PIPELINE_MEGAKERNEL && pipeline != TRH_PIPELINE_MEGAKERNEL_SIMPLE)
+        return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: unknown pipeline");
     c->pipeline = pipeline;
     return TRH_OK;
 }
@@ -611,6 +779,17 @@ int trh_get_stats(trh_context* c, trh_stats* out, int reset) {
         c->kernel_ms = 0.0;
         c->launches = 0;
     }
+    return TRH_OK;
+}
+
+int trh_get_debug_counters(trh_context* c, uint64_t* out, uint32_t n) {
+    if (!c || !out) return fail(TRH_ERR_INVALID_ARG, "trh_get_debug_counters: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    DevCounters h{};
+    HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+    const uint64_t v[5] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen};
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 5 ? v[i] : 0;
     return TRH_OK;
 }
 

@@ -138,6 +138,12 @@ class HipTrace:
         self._check(self._lib.trh_get_stats(self._ctx, C.byref(s), int(reset)))
         return {k: getattr(s, k) for k, _ in capi.trh_stats._fields_}
 
+    def debug_counters(self):
+        """Wave-level iteration counts of the instrumented kernel (see trh_get_debug_counters)."""
+        out = (C.c_uint64 * 5)()
+        self._check(self._lib.trh_get_debug_counters(self._ctx, out, 5))
+        return dict(zip(["wave_inner_iters", "wave_leaf_iters", "wave_shade_calls", "wave_gen_calls", "lanes_gen"], list(out)))
+
     def bvh_info(self):
         b = capi.trh_bvh_info()
         self._check(self._lib.trh_get_bvh_info(self._ctx, C.byref(b)))
