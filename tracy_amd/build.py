@@ -57,6 +57,7 @@ def build_hip(force=False, extra=()):
     deps = _glob_deps(os.path.join(HERE, "csrc", "host"), os.path.join(HERE, "csrc", "hip"), os.path.join(ROOT, "include"))
     if force or _stale(out, deps):
         os.makedirs(LIB, exist_ok=True)
+        extra = list(extra) + os.environ.get("TRH_HIPCC_EXTRA", "").split()
         _run([HIPCC, *HIP_FLAGS, *extra, "-shared",
               os.path.join(HERE, "csrc", "hip", "tracy_hip.hip"),
               os.path.join(HERE, "csrc", "host", "bvh_builder.cpp"), "-o", out])

@@ -132,14 +132,16 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 inv, float t, uint32_t 
 // trav_leaf for a while, do something else (shade other lanes, refill) and come back.
 struct Trav {
     V3 inv;      // Ray ctor: rcp(direction) (src/ray.h:18)
+    V3 oi;       // origin * inv: slab distance = fma(bound, inv, -oi)
     int node;    // >= 0: inner-node record; < 0: leaf link ~((first << 4) | count)
     int sp;      // stack entries in use; < 0 <=> traversal finished
     Hit hit;
 };
 DEVFN bool trav_active(const Trav& tv) { return tv.sp >= 0; }
 
-DEVFN void trav_begin(Trav& tv, V3 d) {
+DEVFN void trav_begin(Trav& tv, V3 o, V3 d) {
     tv.inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    tv.oi = o * tv.inv;
     tv.hit.t = 3.402823466e+38f;  // HitData.t = FLT_MAX (cpu_trace.cpp:119)
     tv.hit.u = tv.hit.v = 0.f;
     tv.hit.prim = -1;
@@ -165,17 +167,36 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
     const float4 nz = sc.nodes[tv.node * 4 + 2];
     const float4 lk = sc.nodes[tv.node * 4 + 3];
     if (STATS) { cnt.box_tests += 2; if (first_active_lane()) cnt.w_inner += 1; }
-    const V3 inv = tv.inv;
-    const float ax0 = (n0.x - o.x) * inv.x, ax1 = (n0.y - o.x) * inv.x;
-    const float ay0 = (n0.z - o.y) * inv.y, ay1 = (n0.w - o.y) * inv.y;
-    const float az0 = (nz.x - o.z) * inv.z, az1 = (nz.y - o.z) * inv.z;
-    const float bx0 = (n1.x - o.x) * inv.x, bx1 = (n1.y - o.x) * inv.x;
-    const float by0 = (n1.z - o.y) * inv.y, by1 = (n1.w - o.y) * inv.y;
-    const float bz0 = (nz.z - o.z) * inv.z, bz1 = (nz.w - o.z) * inv.z;
+#ifdef TRH_EXP_DUP_LOADS   // perturbation experiment: fetch a second (different) record and keep it alive
+    {
+        const int other = tv.node ^ 1;
+        const float4 q0 = sc.nodes[other * 4 + 0], q1 = sc.nodes[other * 4 + 1], q2 = sc.nodes[other * 4 + 2], q3 = sc.nodes[other * 4 + 3];
+        asm volatile("" ::"v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x));
+    }
+#endif
+    // Slab distances in fused form, one v_fma_f32 per plane: fma(bound, inv, -(o*inv)). This rounds
+    // differently from the reference's (bound - o) * inv (collision.h:121-122), which only matters for
+    // WHICH boxes are visited, never for t/u/v: the builder pads every box by 1e-5 of its size plus
+    // 2e-6 of the scene extent, far more than the difference (DESIGN.md "Box test").
+    const V3 inv = tv.inv, oi = tv.oi;
+    const float ax0 = __builtin_fmaf(n0.x, inv.x, -oi.x), ax1 = __builtin_fmaf(n0.y, inv.x, -oi.x);
+    const float ay0 = __builtin_fmaf(n0.z, inv.y, -oi.y), ay1 = __builtin_fmaf(n0.w, inv.y, -oi.y);
+    const float az0 = __builtin_fmaf(nz.x, inv.z, -oi.z), az1 = __builtin_fmaf(nz.y, inv.z, -oi.z);
+    const float bx0 = __builtin_fmaf(n1.x, inv.x, -oi.x), bx1 = __builtin_fmaf(n1.y, inv.x, -oi.x);
+    const float by0 = __builtin_fmaf(n1.z, inv.y, -oi.y), by1 = __builtin_fmaf(n1.w, inv.y, -oi.y);
+    const float bz0 = __builtin_fmaf(nz.z, inv.z, -oi.z), bz1 = __builtin_fmaf(nz.w, inv.z, -oi.z);
     const float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.f));
     const float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), tv.hit.t));
     const float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.f));
     const float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), tv.hit.t));
+#ifdef TRH_EXP_DUP_VALU   // perturbation experiment: ~50 extra dependent-free VALU ops per step
+    {
+        float a = ax0, b = bx0;
+#pragma unroll
+        for (int k = 0; k < 25; ++k) { a = a * 1.0001f + ay0; b = b * 0.9999f + by0; }
+        asm volatile("" ::"v"(a), "v"(b));
+    }
+#endif
     const bool h0 = tmin0 <= tmax0;
     const bool h1 = tmin1 <= tmax1;
     const int c0 = __float_as_int(lk.x), c1 = __float_as_int(lk.y);
@@ -187,14 +208,19 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
     else trav_pop(tv, stack);
 }
 
-// one leaf: Moller-Trumbore over count 48-byte records (collision.h:33-74), then pop.
+// ONE triangle of the current leaf: Moller-Trumbore on a 48-byte record (collision.h:33-74), then
+// advance inside the leaf link ((first + 1) << 4 | (count - 1)) or pop when the leaf is used up.
 // Precondition: tv.sp >= 0 && tv.node < 0.
 template <bool STATS>
 DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__ stack, Counters& cnt) {
-    const uint32_t bits = ~(uint32_t)tv.node;
-    const uint32_t first = bits >> 4, count = bits & 15u;
-    for (uint32_t i = 0; i < count; ++i) {
-        const uint32_t p = first + i;
+    uint32_t bits = ~(uint32_t)tv.node;
+#ifdef TRH_LEAF_WHOLE
+    for (; (bits & 15u) != 0u; bits += 15u) {
+        const uint32_t p = bits >> 4;
+#else
+    const uint32_t p = bits >> 4;
+    if ((bits & 15u) != 0u) {
+#endif
         const float4 r0 = sc.tris[p * 3 + 0];
         const float4 r1 = sc.tris[p * 3 + 1];
         const float4 r2 = sc.tris[p * 3 + 2];
@@ -221,13 +247,18 @@ DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__
             }
         }
     }
+#ifdef TRH_LEAF_WHOLE
     trav_pop(tv, stack);
+#else
+    if ((bits & 15u) > 1u) tv.node = (int)~(bits + 15u);
+    else trav_pop(tv, stack);
+#endif
 }
 
 template <bool STATS>
 DEVFN void intersect(const DevScene& sc, V3 o, V3 d, Hit& hit, int* __restrict__ stack, Counters& cnt) {
     Trav tv;
-    trav_begin(tv, d);
+    trav_begin(tv, o, d);
     while (trav_active(tv)) {
         while (tv.node >= 0) trav_inner<STATS>(sc, o, tv, stack, cnt);
         if (trav_active(tv)) trav_leaf<STATS>(sc, o, d, tv, stack, cnt);
@@ -313,7 +344,9 @@ DEVFN bool shade(const DevScene& sc, PathState& ps, const Hit& hit, Counters& cn
         const float z = 2.f * fastrand(ps.rng) - 1.f;
         const float phi = 2.f * PI * fastrand(ps.rng);
         const float r = __builtin_sqrtf(1.f - pow2(z));
-        const V3 scattered = normal + mk(r * cosf(phi), r * sinf(phi), z);
+        float sphi, cphi;
+        sincosf(phi, &sphi, &cphi);
+        const V3 scattered = normal + mk(r * cphi, r * sphi, z);
         const V3 reflected = reflect(raydir, normal);
         const V3 specular = lerp(reflected, scattered, roughness);
         V3 dir, attenuation;

@@ -51,6 +51,7 @@ struct RenderParams {
     uint32_t tile_w_log2, tile_h_log2;   // wave tile = (1 << tile_w_log2) x (1 << tile_h_log2) pixels
     uint32_t stack_entries;   // LDS stack entries per lane (>= BVH depth)
     uint32_t refill_thresh;   // lanes waiting for shade/refill that end a traversal phase
+    uint32_t sched_beta4;     // inner step is chosen when 4*n_inner >= sched_beta4*n_leaf (0 = while-while)
 };
 
 // device-side counters, one cache line

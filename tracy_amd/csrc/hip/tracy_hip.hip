@@ -131,8 +131,12 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, Re
 // LDS per workgroup: stack_entries x 256 ints (traversal stacks, one bank-conflict-free column
 // per lane) + 4 waves x P x 3 floats (tile accumulators).
 // ---------------------------------------------------------------------------------------
+#ifndef TRH_MEGA_WAVES_PER_EU
+#define TRH_MEGA_WAVES_PER_EU 4
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
+__global__ __launch_bounds__(TRH_BLOCK) __attribute__((amdgpu_waves_per_eu(TRH_MEGA_WAVES_PER_EU, TRH_MEGA_WAVES_PER_EU)))
+void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                                                           DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
     extern __shared__ int s_dyn[];
     int* stack = s_dyn + threadIdx.x;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderPar
         ps.rng = 0;
         ps.bounce = 0;
         Trav tv;
-        tv.inv = mk(0.f, 0.f, 0.f);
+        tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
         tv.node = ~0;
         tv.sp = -1;
         tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderPar
             if (has_path && !trav_active(tv)) {
                 const bool cont = shade<STATS>(sc, ps, tv.hit, cnt);
                 if (cont) {
-                    trav_begin(tv, ps.d);
+                    trav_begin(tv, ps.o, ps.d);
                 } else {
                     __hip_atomic_fetch_add(&wacc[pix * 3 + 0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&wacc[pix * 3 + 1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderPar
                         if (px < sc.width && py < sc.height) {
                             if (STATS) { cnt.l_gen += 1; if (first_active_lane()) cnt.w_gen += 1; }
                             generate(sc, ps, px, py, sample, rp.seed32);
-                            trav_begin(tv, ps.d);
+                            trav_begin(tv, ps.o, ps.d);
                             has_path = true;
                         }   // else: pixel outside the frame (partial edge tile): the item is dropped
                     } else {
@@ -211,12 +215,21 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel(DevScene sc, RenderPar
                 if (__ballot(!exhausted) == 0ull) break;   // tile done
                 continue;                                  // dropped items / paths that ended at once
             }
+            // Majority scheduling: every iteration the wave runs EITHER one inner-node step (for the lanes
+            // standing on an inner record) OR one leaf (for the lanes standing on a leaf), whichever has
+            // more takers (weighted by sched_beta4 / 4). Classic while-while (descend until every lane has
+            // a leaf) makes a 64-wide wave wait for the slowest of 64 descents; beta4 == 0 reproduces it.
             for (;;) {
-                while (tv.node >= 0) trav_inner<STATS>(sc, ps.o, tv, stack, cnt);
-                if (trav_active(tv)) trav_leaf<STATS>(sc, ps.o, ps.d, tv, stack, cnt);
-                tmask = __ballot(trav_active(tv));
-                const unsigned long long waiting = __ballot(has_path && !trav_active(tv));
-                if (tmask == 0ull || (uint32_t)__popcll(waiting) >= rp.refill_thresh) break;
+                const bool act = trav_active(tv);
+                const uint32_t nI = (uint32_t)__popcll(__ballot(act && tv.node >= 0));
+                const uint32_t nL = (uint32_t)__popcll(__ballot(act && tv.node < 0));
+                const uint32_t nW = (uint32_t)__popcll(__ballot(has_path && !act));
+                if ((nI | nL) == 0u || nW >= rp.refill_thresh) break;
+                if (nI != 0u && nI * 4u >= nL * rp.sched_beta4) {
+                    if (act && tv.node >= 0) trav_inner<STATS>(sc, ps.o, tv, stack, cnt);
+                } else {
+                    if (act && tv.node < 0) trav_leaf<STATS>(sc, ps.o, ps.d, tv, stack, cnt);
+                }
             }
         }
         // ---- flush the tile: plain read-modify-write, the tile belongs to this wave
@@ -332,7 +345,9 @@ struct trh_context {
     uint64_t launches = 0;
     trh_bvh_info bvh{};
     int simple_grid = 0, simple_grid_stats = 0;
-    uint32_t refill_thresh = 16;
+    uint32_t refill_thresh = 24;
+    uint32_t sched_beta4 = 4;
+    size_t lds_pad = 0;
 };
 
 namespace {
@@ -401,7 +416,9 @@ int launch_megakernel(trh_context* c, RenderParams rp) {
     rp.tiles_y = ((uint32_t)c->sc.height + (1u << hl) - 1u) >> hl;
     rp.stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u);
     rp.refill_thresh = c->refill_thresh;
-    const size_t lds = ((size_t)rp.stack_entries * TRH_BLOCK + (size_t)TRH_WAVES_PER_BLOCK * (3u << (wl + hl))) * 4;
+    rp.sched_beta4 = c->sched_beta4;
+    size_t lds = ((size_t)rp.stack_entries * TRH_BLOCK + (size_t)TRH_WAVES_PER_BLOCK * (3u << (wl + hl))) * 4;
+    lds += c->lds_pad;   // development knob: lowers occupancy to measure latency sensitivity
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS>, TRH_BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
@@ -478,6 +495,11 @@ int trh_init(int device, trh_context** ctx_out) {
     if (const char* e = getenv("TRH_REFILL_THRESH")) {   // development knob
         const int v = atoi(e);
         if (v >= 1 && v <= 64) c->refill_thresh = (uint32_t)v;
+    }
+    if (const char* e = getenv("TRH_LDS_PAD")) c->lds_pad = (size_t)atoi(e);
+    if (const char* e = getenv("TRH_SCHED_BETA4")) {     // development knob
+        const int v = atoi(e);
+        if (v >= 0 && v <= 256) c->sched_beta4 = (uint32_t)v;
     }
     *ctx_out = c;
     return TRH_OK;

@@ -45,6 +45,7 @@ struct Builder {
     std::vector<Ref> refs;
     Result& out;
     float root_area = 1.f;
+    float scene_extent = 0.f;
 
     Builder(const std::vector<InputTriangle>& t, Result& r) : in(t), out(r) {}
 
@@ -154,11 +155,11 @@ struct Builder {
         return me;
     }
 
-    static void pad(Box& b) {
+    void pad(Box& b) const {
         // conservative inflation: the slab test and Moller-Trumbore round differently
         for (int a = 0; a < 3; ++a) {
             float m = std::max(std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a])), b.mx[a] - b.mn[a]);
-            float d = 1e-5f * m + 1e-7f;
+            float d = 1e-5f * m + 2e-6f * scene_extent + 1e-7f;
             b.mn[a] -= d;
             b.mx[a] += d;
         }
@@ -190,6 +191,8 @@ struct Builder {
             all.grow(r.box);
         }
         root_area = std::max(all.half_area(), 1e-30f);
+        for (int a = 0; a < 3; ++a) scene_extent = std::max(scene_extent, std::max(all.mx[a] - all.mn[a], std::max(std::fabs(all.mn[a]), std::fabs(all.mx[a]))));
+        if (in.empty()) scene_extent = 0.f;
         out.nodes.clear();
         out.tris.clear();
         out.prim_index.clear();
