@@ -64,6 +64,16 @@ def build_hip(force=False, extra=()):
     return out
 
 
+def build_cli(force=False):
+    """Headless C++ host (twin of the reference's main loop) linked against the two C-ABI libraries."""
+    out = os.path.join(LIB, "tracy_hip_cli")
+    deps = _glob_deps(os.path.join(HERE, "csrc", "host"), os.path.join(HERE, "csrc", "app"), os.path.join(ROOT, "include"))
+    if force or _stale(out, deps):
+        _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", os.path.join(HERE, "csrc", "app", "tracy_hip_cli.cpp"),
+              "-L", LIB, "-ltracy_hip", "-ltracy_scene", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", out])
+    return out
+
+
 def build_oracle(force=False):
     if force:
         _run(["make", "-C", os.path.join(ROOT, "oracle"), "clean"])
@@ -74,16 +84,19 @@ def build_oracle(force=False):
 def build_all(force=False):
     build_scene(force)
     build_hip(force)
+    build_cli(force)
     build_oracle(force)
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["scene", "hip", "oracle"]
+    what = sys.argv[1:] or ["scene", "hip", "cli", "oracle"]
     force = "--force" in what
     for w in what:
         if w == "scene":
             build_scene(force)
         elif w == "hip":
             build_hip(force)
+        elif w == "cli":
+            build_cli(force)
         elif w == "oracle":
             build_oracle(force)

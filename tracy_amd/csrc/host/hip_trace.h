@@ -1,0 +1,239 @@
+// hip_trace.h -- HipTrace: the `-kernel hip` render module, host side (C++, no HIP headers).
+//
+// A thin class over the C ABI of include/tracy_hip.h with the life cycle of the reference's
+// modules: CpuTrace (src/kernels/raytracing/software/cpu_trace.{h,cpp}) and CUDATrace
+// (src/kernels/raytracing/cuda/cuda_trace.cpp:28-62). It is a template on the scene type so that
+// the same code serves
+//   * the reference's `Scene` (src/scene.h): the generic FlattenScene below reads it through the
+//     accessors GetObjectCount/GetObject/GetMaterials/GetTextures/GetCamera (scene.h:36-60,
+//     mesh.h:83-103, material.h:54-101, texture.h:59-82, camera.h:57-67), and
+//   * this repository's standalone host scene (host_scene.h), which already owns a trh_scene_desc.
+// Error behaviour follows the reference: Startup returns false (main then logs "Kernel failed to
+// initialize", win_raytracer.cpp:572-575); run-time device errors are logged and abort, like
+// CUDAAssert (cuda_log.h:19-32). There is no CPU fallback.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "../../../include/tracy_hip.h"
+#include "tracy_module.h"
+
+namespace tracy_hip {
+
+// Owns the POD arrays a trh_scene_desc points to.
+struct FlatScene {
+    std::vector<float> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<trh_mesh> meshes;
+    std::vector<trh_material> materials;
+    std::vector<trh_texture> textures;
+    trh_scene_desc desc{};
+    float eye[3]{};
+    float inv_view_proj[16]{};
+};
+
+// 4x4 column-major helpers (Camera keeps inverse(projection * view) private, camera.h:84)
+inline void Mul4x4(const float* a, const float* b, float* r) {
+    for (int c = 0; c < 4; ++c)
+        for (int k = 0; k < 4; ++k) r[c * 4 + k] = a[0 * 4 + k] * b[c * 4 + 0] + a[1 * 4 + k] * b[c * 4 + 1] + a[2 * 4 + k] * b[c * 4 + 2] + a[3 * 4 + k] * b[c * 4 + 3];
+}
+inline bool Invert4x4(const float* m, float* out) {
+    double a[16], inv[16];
+    for (int i = 0; i < 16; ++i) a[i] = m[i];
+    inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+    inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+    inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+    inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+    inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+    inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+    inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+    inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+    inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+    inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+    inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+    inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+    inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+    inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+    inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+    inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+    const double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+    if (det == 0.0) return false;
+    for (int i = 0; i < 16; ++i) out[i] = static_cast<float>(inv[i] / det);
+    return true;
+}
+
+template <class SceneT>
+bool FlattenCamera(const SceneT& scene, FlatScene& out);
+
+// Generic flattening of a scene that offers the reference's accessors (src/scene.h:36-60).
+// `Vertex` there is 14 packed floats (src/vertex.h:36-40) == TRH_VERTEX_FLOATS.
+template <class SceneT>
+bool FlattenScene(const SceneT& scene, FlatScene& out) {
+    out = FlatScene{};
+    for (uint32_t i = 0; i < scene.GetObjectCount(); ++i) {
+        const auto& mesh = scene.GetObject(i);
+        static_assert(sizeof(*mesh.GetVertices()) == TRH_VERTEX_FLOATS * sizeof(float), "Vertex must be 14 packed floats");
+        trh_mesh m{};
+        m.first_vertex = static_cast<uint32_t>(out.vertices.size() / TRH_VERTEX_FLOATS);
+        m.vertex_count = mesh.GetVertexCount();
+        m.first_index = static_cast<uint32_t>(out.indices.size());
+        m.index_count = mesh.GetIndexCount();
+        m.material = mesh.GetMaterial();
+        const auto& bb = mesh.GetAABB();
+        m.aabb_min[0] = bb.minbound.x; m.aabb_min[1] = bb.minbound.y; m.aabb_min[2] = bb.minbound.z;
+        m.aabb_max[0] = bb.maxbound.x; m.aabb_max[1] = bb.maxbound.y; m.aabb_max[2] = bb.maxbound.z;
+        const float* v = reinterpret_cast<const float*>(mesh.GetVertices());
+        out.vertices.insert(out.vertices.end(), v, v + static_cast<size_t>(m.vertex_count) * TRH_VERTEX_FLOATS);
+        out.indices.insert(out.indices.end(), mesh.GetIndices(), mesh.GetIndices() + m.index_count);
+        out.meshes.push_back(m);
+    }
+    for (const auto& src : scene.GetMaterials()) {
+        trh_material m{};
+        const auto& al = src.GetAlbedo();
+        const auto& em = src.GetEmissive();
+        m.albedo[0] = al.x; m.albedo[1] = al.y; m.albedo[2] = al.z;
+        m.roughness = src.GetRoughness();
+        m.metalness = src.GetMetalness();
+        m.ior = src.GetRefractiveIndex();
+        m.emissive[0] = em.x; m.emissive[1] = em.y; m.emissive[2] = em.z;
+        m.translucent = src.GetTranslucent();
+        using MatT = typename std::decay<decltype(src)>::type;
+        for (int k = 0; k < TRH_TEX_COUNT; ++k) m.tex[k] = src.GetTexture(static_cast<typename MatT::TextureID>(k));  // UINT32_MAX when unset
+        out.materials.push_back(m);
+    }
+    for (const auto& t : scene.GetTextures()) {
+        trh_texture d{};
+        d.width = t.GetWidth();
+        d.height = t.GetHeight();
+        d.rgba = reinterpret_cast<const float*>(t.GetPixels());   // vec4* RGBA32F (texture.h:74-77)
+        out.textures.push_back(d);
+    }
+    trh_scene_desc& d = out.desc;
+    d.vertices = out.vertices.data();
+    d.vertex_count = static_cast<uint32_t>(out.vertices.size() / TRH_VERTEX_FLOATS);
+    d.indices = out.indices.data();
+    d.index_count = static_cast<uint32_t>(out.indices.size());
+    d.meshes = out.meshes.data();
+    d.mesh_count = static_cast<uint32_t>(out.meshes.size());
+    d.materials = out.materials.data();
+    d.material_count = static_cast<uint32_t>(out.materials.size());
+    d.textures = out.textures.data();
+    d.texture_count = static_cast<uint32_t>(out.textures.size());
+    d.width = scene.GetWidth();
+    d.height = scene.GetHeight();
+    d.max_bounces = 5;              // TRACY_MAX_BOUNCES (CMakeLists.txt:110)
+    d.flags = TRH_FLAG_DEFAULT;     // TRACY_RUSSIAN_ROULETTE ON (CMakeLists.txt:113)
+    return FlattenCamera(scene, out);
+}
+
+template <class SceneT>
+bool FlattenCamera(const SceneT& scene, FlatScene& out) {
+    const auto& cam = scene.GetCamera();
+    const auto& e = cam.GetPosition();
+    out.eye[0] = e.x; out.eye[1] = e.y; out.eye[2] = e.z;
+    float pv[16];
+    Mul4x4(reinterpret_cast<const float*>(&cam.GetProjection()), reinterpret_cast<const float*>(&cam.GetView()), pv);
+    return Invert4x4(pv, out.inv_view_proj);
+}
+
+template <class SceneT, class Base = TracyModuleT<SceneT>, class WindowT = WindowHandle, class EventT = TracyEvent>
+class HipTraceT final : public Base {
+public:
+    // samples traced per OnUpdate; the reference traces 1 (cpu_trace.cpp:55-65)
+    explicit HipTraceT(int device = 0, uint32_t spp_per_update = 1) : device_(device), spp_per_update_(spp_per_update) {}
+
+    bool Startup(const WindowT in_Window, const SceneT& in_Scene) override {
+        (void)in_Window;
+        if (trh_init(device_, &ctx_) != TRH_OK) return Fail("trh_init");
+        FlatScene flat;
+        if (!FlattenScene(in_Scene, flat)) return Fail("FlattenScene");
+        if (trh_scene_upload(ctx_, &flat.desc) != TRH_OK) return Fail("trh_scene_upload");
+        if (trh_set_camera(ctx_, flat.eye, flat.inv_view_proj) != TRH_OK) return Fail("trh_set_camera");
+        width_ = flat.desc.width;
+        height_ = flat.desc.height;
+        image_.assign(static_cast<size_t>(width_) * height_ * 4, 0.f);
+        next_sample_ = 0;
+        return true;
+    }
+
+    void Shutdown() override {
+        if (ctx_) trh_shutdown(ctx_);
+        ctx_ = nullptr;
+    }
+
+    void OnUpdate(const SceneT& in_Scene, float in_DeltaTime) override {
+        (void)in_DeltaTime;
+        if (camera_dirty_) {   // pattern of CUDADetails::Update (cuda_details.cpp:206-215)
+            FlatScene cam;
+            if (FlattenCamera(in_Scene, cam)) Check(trh_set_camera(ctx_, cam.eye, cam.inv_view_proj), "trh_set_camera");
+            Check(trh_reset_accumulation(ctx_), "trh_reset_accumulation");
+            next_sample_ = 0;
+            camera_dirty_ = false;
+        }
+        Check(trh_render(ctx_, next_sample_, spp_per_update_, kSeed), "trh_render");
+        Check(trh_synchronize(ctx_), "trh_synchronize");   // OnUpdate is synchronous: main() times it (win_raytracer.cpp:511-515)
+        next_sample_ += spp_per_update_;
+    }
+
+    // The reference modules present into the window here (cpu_details.cpp:245-248). Headless: the
+    // linear mean image is resolved and kept for the caller (GetImage).
+    void OnRender(const WindowT in_Window) override {
+        (void)in_Window;
+        uint64_t n = 0;
+        Check(trh_resolve(ctx_, image_.data(), &n), "trh_resolve");
+    }
+
+    void OnEvent(EventT in_Event, const WindowT in_Window, const SceneT& in_Scene) override {
+        (void)in_Window;
+        (void)in_Scene;
+        if (in_Event == EventT::eCameraCut) camera_dirty_ = true;   // cpu_trace.cpp:76-78
+    }
+
+    const char* GetModuleName() const override { return "HIP Raytracing [MI355X gfx950]"; }
+
+    // u32 in the interface (src/module.h:53); saturates instead of wrapping
+    uint32_t GetRayCount(bool in_ShouldReset = false) override {
+        trh_stats st{};
+        Check(trh_get_stats(ctx_, &st, in_ShouldReset ? 1 : 0), "trh_get_stats");
+        return st.rays > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(st.rays);
+    }
+    uint64_t GetRayCount64(bool in_ShouldReset = false) {
+        trh_stats st{};
+        Check(trh_get_stats(ctx_, &st, in_ShouldReset ? 1 : 0), "trh_get_stats");
+        return st.rays;
+    }
+
+    const float* GetImage() const { return image_.data(); }   // width*height*4, row 0 = bottom row
+    uint32_t GetWidth() const { return width_; }
+    uint32_t GetHeight() const { return height_; }
+    uint32_t GetSampleCount() const { return next_sample_; }
+    trh_context* GetContext() { return ctx_; }
+
+private:
+    static constexpr uint64_t kSeed = 0xABCDEFull;   // initrand() (src/random.h:66-69)
+
+    bool Fail(const char* what) {
+        fprintf(stderr, "[HipTrace] %s failed: %s\n", what, trh_last_error());
+        if (ctx_) trh_shutdown(ctx_);
+        ctx_ = nullptr;
+        return false;
+    }
+    void Check(int rc, const char* what) {
+        if (rc != TRH_OK) {   // as CUDAAssert (cuda_log.h:19-32): log and stop
+            fprintf(stderr, "[HipTrace] %s failed (%d): %s\n", what, rc, trh_last_error());
+            exit(EXIT_FAILURE);
+        }
+    }
+
+    int device_ = 0;
+    uint32_t spp_per_update_ = 1;
+    trh_context* ctx_ = nullptr;
+    uint32_t width_ = 0, height_ = 0, next_sample_ = 0;
+    bool camera_dirty_ = false;
+    std::vector<float> image_;
+};
+
+}  // namespace tracy_hip
