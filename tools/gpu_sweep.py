@@ -19,7 +19,7 @@ for a in sys.argv[1:]:
     configs.append(a)
 for cfg in configs or ["dragon:1920:1080:64"]:
     scene, w, h, spp = cfg.split(":")
-    for pipe, thr, beta in [(2, 0, 0)] + [(0, t, b) for t in (1, 8, 16, 32) for b in (0, 1, 2, 4, 8, 16)]:
+    for pipe, thr, beta in [(2, 0, 4), (0, 24, 4), (1, 8, 4), (1, 16, 4), (1, 24, 4), (1, 32, 4)]:
         env = dict(os.environ); env["TRH_REFILL_THRESH"] = str(thr or 16); env["TRH_SCHED_BETA4"] = str(beta)
         out = subprocess.run([sys.executable, __file__, "child", scene, w, h, spp, str(pipe)], env=env, capture_output=True, text=True, timeout=300)
         print(cfg, "pipeline", pipe, "thresh", thr, "beta4", beta, out.stdout.strip() or out.stderr[-300:], flush=True)

@@ -21,7 +21,7 @@ for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), rec
 print("## PMC (average per dispatch; one rocprofv3 --pmc run per counter group)\n")
 out = {}
 for k, cs in agg.items():
-    if "megakernel" not in k and "k_extend" not in k and "k_shade" not in k and "k_generate" not in k:
+    if "megakernel" not in k and "k_wf_extend" not in k and "k_wf_shade" not in k and "k_wf_generate" not in k:
         continue
     print(f"### {k[:90]}\n")
     print("| counter | avg per dispatch | dispatches |\n|---|---|---|")

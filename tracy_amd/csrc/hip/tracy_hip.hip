@@ -293,6 +293,8 @@ __global__ void k_resolve(const float4* __restrict__ accum, float4* __restrict__
     out[p] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w);
 }
 
+#include "wavefront.h"
+
 // =====================================================================================
 // host side of the C ABI
 // =====================================================================================
@@ -348,6 +350,11 @@ struct trh_context {
     uint32_t refill_thresh = 24;
     uint32_t sched_beta4 = 4;
     size_t lds_pad = 0;
+    // wavefront pipeline state (allocated on first use)
+    WfBuffers wf{};
+    std::vector<void*> wf_allocs;
+    size_t wf_item_capacity = 0;
+    uint32_t wf_pool_limit = 1u << 22;
 };
 
 namespace {
@@ -366,6 +373,10 @@ int dev_alloc_copy(trh_context* c, const T* host, size_t count, T** out) {
 int free_scene(trh_context* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
+    for (void* p : c->wf_allocs) (void)hipFree(p);
+    c->wf_allocs.clear();
+    c->wf = WfBuffers{};
+    c->wf_item_capacity = 0;
     c->accum = nullptr;
     c->accum_internal = nullptr;
     c->resolved = nullptr;
@@ -429,6 +440,95 @@ int launch_megakernel(trh_context* c, RenderParams rp) {
     return TRH_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// wavefront pipeline: host orchestration (kernels in wavefront.h)
+// ---------------------------------------------------------------------------------------
+int wf_ensure(trh_context* c, size_t items) {
+    const uint32_t npix = (uint32_t)(c->sc.width * c->sc.height);
+    if (c->wf.pool == 0) {
+        uint32_t pool = c->wf_pool_limit;
+        const uint64_t want = ((uint64_t)npix * 4 + 255) / 256 * 256;   // small frames: a few samples per pixel in flight
+        if (want < pool) pool = (uint32_t)want;
+        if (pool < 1024) pool = 1024;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, (size_t)pool * 5 * sizeof(float4)));
+        c->wf_allocs.push_back(p);
+        c->wf.st = (float4*)p;
+        uint32_t** qs[3] = {&c->wf.q_a, &c->wf.q_b, &c->wf.q_free};
+        for (auto q : qs) {
+            HIP_TRY(hipMalloc(&p, (size_t)pool * sizeof(uint32_t)));
+            c->wf_allocs.push_back(p);
+            *q = (uint32_t*)p;
+        }
+        HIP_TRY(hipMalloc(&p, 256));
+        c->wf_allocs.push_back(p);
+        c->wf.ctl = (WfCtl*)p;
+        c->wf.pool = pool;
+    }
+    if (items > c->wf_item_capacity) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->wf.item_rad) {
+            (void)hipFree(c->wf.item_rad);
+            c->wf_allocs.erase(std::remove(c->wf_allocs.begin(), c->wf_allocs.end(), (void*)c->wf.item_rad), c->wf_allocs.end());
+            c->wf.item_rad = nullptr;
+        }
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, items * sizeof(float4)));
+        c->wf_allocs.push_back(p);
+        c->wf.item_rad = (float4*)p;
+        c->wf_item_capacity = items;
+    }
+    return TRH_OK;
+}
+
+int launch_wavefront(trh_context* c, const RenderParams& rp) {
+    const uint32_t npix = (uint32_t)(c->sc.width * c->sc.height);
+    const uint64_t kItemBudget = 1ull << 28;   // 4 GiB of float4 per batch at most
+    uint32_t batch_spp = (uint32_t)std::min<uint64_t>(rp.spp_count, std::max<uint64_t>(1, kItemBudget / npix));
+    int rc = wf_ensure(c, (size_t)npix * batch_spp);
+    if (rc) return rc;
+    const uint32_t pool = c->wf.pool;
+    const uint32_t stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u);
+    const size_t lds = (size_t)stack_entries * TRH_BLOCK * 4;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend, TRH_BLOCK, lds));
+    if (per_cu < 1) per_cu = 1;
+    const int extend_grid = per_cu * c->num_cus;
+    const dim3 pool_grid((pool + 255) / 256);
+    for (uint32_t done = 0; done < rp.spp_count; done += batch_spp) {
+        const uint32_t spp = std::min(batch_spp, rp.spp_count - done);
+        const uint32_t items = npix * spp;
+        WfCtl init{};
+        init.n_free = pool;
+        init.items_end = items;
+        HIP_TRY(hipMemcpyAsync(c->wf.ctl, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // `init` lives on this stack frame
+        hipLaunchKernelGGL(k_wf_init_free, pool_grid, dim3(256), 0, c->stream, c->wf.q_free, pool);
+        uint32_t* q_cur = c->wf.q_a;
+        uint32_t* q_next = c->wf.q_b;
+        const uint32_t min_iters = items / pool;   // the item cursor cannot reach the end earlier
+        for (uint32_t iter = 0;; ++iter) {
+            hipLaunchKernelGGL(k_wf_generate, pool_grid, dim3(256), 0, c->stream, c->sc, c->wf, q_next, rp.spp_begin + done, rp.seed32);
+            hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, c->stream, c->wf);
+            std::swap(q_cur, q_next);
+            hipLaunchKernelGGL(k_wf_extend, dim3(extend_grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, c->wf, q_cur, stack_entries,
+                               c->refill_thresh, c->sched_beta4);
+            hipLaunchKernelGGL(k_wf_shade, dim3((pool + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, c->stream, c->sc, c->wf, q_cur, q_next, c->counters);
+            HIP_TRY(hipGetLastError());
+            if (iter >= min_iters) {
+                WfCtl h{};
+                HIP_TRY(hipMemcpyAsync(&h, c->wf.ctl, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (h.n_next == 0 && h.item_cursor >= h.items_end) break;
+            }
+            if (iter > 1000000u) return fail(TRH_ERR_STATE, "wavefront pipeline did not terminate");
+        }
+        hipLaunchKernelGGL(k_wf_accumulate, dim3((npix + 255) / 256), dim3(256), 0, c->stream, c->wf.item_rad, c->accum, npix, spp);
+        HIP_TRY(hipGetLastError());
+    }
+    return TRH_OK;
+}
+
 int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed, bool stats) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_render: ctx is NULL");
     if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_render: scene and camera must be uploaded first");
@@ -444,7 +544,8 @@ int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
     int rc;
-    if (c->pipeline == TRH_PIPELINE_MEGAKERNEL_SIMPLE) rc = stats ? launch_megakernel_simple<true>(c, rp) : launch_megakernel_simple<false>(c, rp);
+    if (c->pipeline == TRH_PIPELINE_WAVEFRONT && !stats) rc = launch_wavefront(c, rp);
+    else if (c->pipeline == TRH_PIPELINE_MEGAKERNEL_SIMPLE) rc = stats ? launch_megakernel_simple<true>(c, rp) : launch_megakernel_simple<false>(c, rp);
     else rc = stats ? launch_megakernel<true>(c, rp) : launch_megakernel<false>(c, rp);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -495,6 +596,10 @@ int trh_init(int device, trh_context** ctx_out) {
     if (const char* e = getenv("TRH_REFILL_THRESH")) {   // development knob
         const int v = atoi(e);
         if (v >= 1 && v <= 64) c->refill_thresh = (uint32_t)v;
+    }
+    if (const char* e = getenv("TRH_WF_POOL_LOG2")) {      // development knob
+        const int v = atoi(e);
+        if (v >= 8 && v <= 26) c->wf_pool_limit = 1u << v;
     }
     if (const char* e = getenv("TRH_LDS_PAD")) c->lds_pad = (size_t)atoi(e);
     if (const char* e = getenv("TRH_SCHED_BETA4")) {     // development knob
@@ -688,7 +793,7 @@ int trh_reset_accumulation(trh_context* c) {
 
 int trh_set_pipeline(trh_context* c, int pipeline) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: ctx is NULL");
-    if (pipeline != TRH_PIPELINE_MEGAKERNEL && pipeline != TRH_PIPELINE_MEGAKERNEL_SIMPLE)
+    if (pipeline != TRH_PIPELINE_MEGAKERNEL && pipeline != TRH_PIPELINE_MEGAKERNEL_SIMPLE && pipeline != TRH_PIPELINE_WAVEFRONT)
         return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: unknown pipeline");
     c->pipeline = pipeline;
     return TRH_OK;
