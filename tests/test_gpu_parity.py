@@ -148,6 +148,25 @@ def test_wavefront_golden_parity(hip, scene_loader):
     assert np.allclose(one[..., :3], g["s0"][..., :3], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("w,h,spp", [(100, 50, 3), (100, 50, 9), (37, 23, 1), (8, 8, 70), (1, 1, 5)])
+def test_ragged_frames_and_small_sample_counts(hip, scene_loader, w, h, spp):
+    """Frames that are not multiples of the 8x8 / 16x16 wave tiles, and per-call sample counts on both
+    sides of the tile-size switch: the accumulated sum must equal the sum of the single samples."""
+    sc = scene_loader("cornell", w, h)
+    mod = hip(sc)
+    mod.render(2, spp)
+    img, n = mod.resolve()
+    assert n == spp and (img[..., 3] == spp).all()
+    acc = np.zeros((h, w, 3), dtype=np.float64)
+    rays = 0
+    for s in range(2, 2 + spp):
+        r = mod.sample_radiance(s)
+        acc += r[..., :3]
+        rays += int(r[..., 3].sum())
+    assert np.allclose(img[..., :3], acc / spp, rtol=1e-5, atol=1e-6)
+    assert mod.stats()["rays"] == rays
+
+
 def test_camera_cut_resets_accumulation(hip, scene_loader):
     sc = scene_loader("cornell", 64, 36)
     mod = hip(sc)

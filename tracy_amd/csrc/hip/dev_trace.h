@@ -133,7 +133,7 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 inv, float t, uint32_t 
 struct Trav {
     V3 inv;      // Ray ctor: rcp(direction) (src/ray.h:18)
     V3 oi;       // origin * inv: slab distance = fma(bound, inv, -oi)
-    int node;    // >= 0: inner-node record; < 0: leaf link ~((first << 4) | count)
+    int node;    // >= 0: inner-node record; < -1: leaf link ~((first << 4) | count); -1: nothing to traverse
     int sp;      // stack entries in use; < 0 <=> traversal finished
     Hit hit;
 };
@@ -150,13 +150,13 @@ DEVFN void trav_begin(Trav& tv, V3 o, V3 d) {
     // comparison is false in the reference, i.e. a miss
     const bool nan = d.x != d.x;
     tv.sp = nan ? -1 : 0;
-    tv.node = nan ? ~0 : 0;
+    tv.node = nan ? -1 : 0;
 }
 
 DEVFN void trav_pop(Trav& tv, const int* __restrict__ stack) {
     --tv.sp;
     const int top = stack[(tv.sp < 0 ? 0 : tv.sp) * TRH_BLOCK];
-    tv.node = tv.sp < 0 ? ~0 : top;   // ~0 = empty leaf: nothing left to do
+    tv.node = tv.sp < 0 ? -1 : top;   // -1: traversal finished
 }
 
 // one inner-node record: one 64-byte fetch, two slab tests. Precondition: tv.node >= 0.

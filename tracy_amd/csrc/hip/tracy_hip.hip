@@ -131,6 +131,9 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, Re
 // LDS per workgroup: stack_entries x 256 ints (traversal stacks, one bank-conflict-free column
 // per lane) + 4 waves x P x 3 floats (tile accumulators).
 // ---------------------------------------------------------------------------------------
+#ifndef TRH_INNER_REPEAT
+#define TRH_INNER_REPEAT 2
+#endif
 #ifndef TRH_MEGA_WAVES_PER_EU
 #define TRH_MEGA_WAVES_PER_EU 4
 #endif
@@ -165,7 +168,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
         ps.bounce = 0;
         Trav tv;
         tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
-        tv.node = ~0;
+        tv.node = -1;
         tv.sp = -1;
         tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
         uint32_t pix = 0;           // pixel-in-tile of the item this lane works on
@@ -219,16 +222,19 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             // standing on an inner record) OR one leaf (for the lanes standing on a leaf), whichever has
             // more takers (weighted by sched_beta4 / 4). Classic while-while (descend until every lane has
             // a leaf) makes a 64-wide wave wait for the slowest of 64 descents; beta4 == 0 reproduces it.
+            // Lane state is readable from tv.node alone: >= 0 inner record, < -1 leaf, == -1 nothing to
+            // traverse (finished, or no path), so each census is one v_cmp + s_bcnt1.
+            const uint32_t nP = (uint32_t)__popcll(__ballot(has_path));   // constant during the traversal phase
             for (;;) {
-                const bool act = trav_active(tv);
-                const uint32_t nI = (uint32_t)__popcll(__ballot(act && tv.node >= 0));
-                const uint32_t nL = (uint32_t)__popcll(__ballot(act && tv.node < 0));
-                const uint32_t nW = (uint32_t)__popcll(__ballot(has_path && !act));
-                if ((nI | nL) == 0u || nW >= rp.refill_thresh) break;
+                const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
+                const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
+                if ((nI | nL) == 0u || nP - nI - nL >= rp.refill_thresh) break;
                 if (nI != 0u && nI * 4u >= nL * rp.sched_beta4) {
-                    if (act && tv.node >= 0) trav_inner<STATS>(sc, ps.o, tv, stack, cnt);
+#pragma unroll
+                    for (int r = 0; r < TRH_INNER_REPEAT; ++r)
+                        if (tv.node >= 0) trav_inner<STATS>(sc, ps.o, tv, stack, cnt);
                 } else {
-                    if (act && tv.node < 0) trav_leaf<STATS>(sc, ps.o, ps.d, tv, stack, cnt);
+                    if (tv.node < -1) trav_leaf<STATS>(sc, ps.o, ps.d, tv, stack, cnt);
                 }
             }
         }
@@ -348,7 +354,7 @@ struct trh_context {
     trh_bvh_info bvh{};
     int simple_grid = 0, simple_grid_stats = 0;
     uint32_t refill_thresh = 24;
-    uint32_t sched_beta4 = 4;
+    uint32_t sched_beta4 = 6;
     size_t lds_pad = 0;
     // wavefront pipeline state (allocated on first use)
     WfBuffers wf{};

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers 
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
     Trav tv;
     tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
-    tv.node = ~0;
+    tv.node = -1;
     tv.sp = -1;
     tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
     uint32_t chunk_pos = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the queue
@@ -146,16 +146,15 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers 
         }
         if (__ballot(has_ray) == 0ull) break;   // every lane drained: all waves reach this exit
         // ---- majority-vote traversal until enough lanes are idle again
+        const uint32_t nP = (uint32_t)__popcll(__ballot(has_ray));
         for (;;) {
-            const bool act = trav_active(tv);
-            const uint32_t nI = (uint32_t)__popcll(__ballot(act && tv.node >= 0));
-            const uint32_t nL = (uint32_t)__popcll(__ballot(act && tv.node < 0));
-            const uint32_t nW = (uint32_t)__popcll(__ballot(has_ray && !act));
-            if ((nI | nL) == 0u || nW >= refill_thresh) break;
+            const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
+            const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
+            if ((nI | nL) == 0u || nP - nI - nL >= refill_thresh) break;
             if (nI != 0u && nI * 4u >= nL * sched_beta4) {
-                if (act && tv.node >= 0) trav_inner<false>(sc, o, tv, stack, cnt);
+                if (tv.node >= 0) trav_inner<false>(sc, o, tv, stack, cnt);
             } else {
-                if (act && tv.node < 0) trav_leaf<false>(sc, o, d, tv, stack, cnt);
+                if (tv.node < -1) trav_leaf<false>(sc, o, d, tv, stack, cnt);
             }
         }
     }

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace bvh {
@@ -31,8 +32,8 @@ struct Ref {
     uint32_t idx;
 };
 
-constexpr float kCostTraverse = 1.0f;
-constexpr float kCostIntersect = 1.0f;
+float kCostTraverse = 0.5f;   // one inner-record step (two slab tests)
+constexpr float kCostIntersect = 1.0f;   // one Moller-Trumbore test
 
 int levels_needed(size_t n) {  // inner-record levels a median-split subtree of n prims needs
     int l = 0;
@@ -198,7 +199,7 @@ struct Builder {
         out.prim_index.clear();
         out.tris.reserve(in.size() * 12);
         out.prim_index.reserve(in.size());
-        const int empty_leaf = ~0;  // first 0, count 0
+        const int empty_leaf = ~(1 << 4);  // first 1, count 0 (never -1: the kernels read a link of -1 as "nothing to traverse")
         if (in.empty()) {
             out.nodes.resize(16, 0.f);
             write_record(0, Box{}, Box{}, empty_leaf, empty_leaf);
@@ -221,6 +222,7 @@ struct Builder {
 
 void build(const std::vector<InputTriangle>& tris, Result& out) {
     out = Result{};
+    if (const char* e = getenv("TRH_SAH_CT")) { const float v = (float)atof(e); if (v > 0.f) kCostTraverse = v; }   // development knob
     Builder b(tris, out);
     b.run();
 }

@@ -27,7 +27,8 @@ struct InputTriangle {
 //   [4..7]   c1.min.x c1.max.x c1.min.y c1.max.y
 //   [8..11]  c0.min.z c0.max.z c1.min.z c1.max.z
 //   [12..15] child0 child1 (int bits) 0 0
-// child >= 0: index of an inner-node record; child < 0: leaf, ~child = (first_prim << 4) | count
+// child >= 0: index of an inner-node record; child < -1: leaf, ~child = (first_prim << 4) | count
+// (count may be 0 for the padding leaf of tiny scenes; the value -1 is never produced)
 struct Result {
     std::vector<float> nodes;          // 16 floats per inner node, node 0 is the root
     std::vector<float> tris;           // 12 floats per primitive in leaf order: v0.xyz id | e1.xyz 0 | e2.xyz 0
