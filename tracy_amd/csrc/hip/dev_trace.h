@@ -25,6 +25,7 @@ constexpr float PI = 3.1415926535897932f;
 constexpr float EPS = 1.e-8f;
 
 struct V3 { float x, y, z; };
+typedef _Float16 H2 __attribute__((ext_vector_type(2)));
 DEVFN V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 DEVFN V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 DEVFN V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -107,7 +108,7 @@ DEVFN void camera_ray(const DevScene& sc, float s, float t, V3& o, V3& d) {
 //   * different meshes, |dt| <= 1e-5 t -> replay the reference's pairwise decision: the later mesh b
 //     beats the earlier mesh a iff t_b <= t_a and slab_tmin(AABB_b) < t_a. This is what decides
 //     coincident coplanar faces of two objects (data/scenes/random.scn: light box on a wall).
-DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 inv, float t, uint32_t id, const Hit& hit) {
+DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 d, float t, uint32_t id, const Hit& hit) {
     if (t < EPS) return false;
     const uint32_t mc = id >> 24, mh = hit.id >> 24;
     if (mc == mh || !(fabsf(t - hit.t) <= 1e-5f * hit.t)) return t < hit.t || (t == hit.t && id > hit.id);
@@ -116,6 +117,7 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 inv, float t, uint32_t 
     const float t_b = c_later ? t : hit.t;
     const uint32_t mb = c_later ? mc : mh;
     const float4 bmn = sc.mesh_aabb[mb * 2 + 0], bmx = sc.mesh_aabb[mb * 2 + 1];
+    const V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);   // Ray ctor (src/ray.h:18); rare path, not worth registers
     const float x0 = (bmn.x - o.x) * inv.x, x1 = (bmx.x - o.x) * inv.x;
     const float y0 = (bmn.y - o.y) * inv.y, y1 = (bmx.y - o.y) * inv.y;
     const float z0 = (bmn.z - o.z) * inv.z, z1 = (bmx.z - o.z) * inv.z;
@@ -127,21 +129,35 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 inv, float t, uint32_t 
 }
 
 // ------------------------------------------------------------------ nearest hit
-// Resumable stack traversal of the 64-byte BVH2 records. The state lives in registers (Trav) plus
+// Resumable stack traversal of the BVH2 records (32-byte fp16 form; 64-byte fp32 form with -DTRH_NODE32). The state lives in registers (Trav) plus
 // this lane's LDS stack column (entry i at stack[i * TRH_BLOCK]); a kernel may run trav_inner /
 // trav_leaf for a while, do something else (shade other lanes, refill) and come back.
 struct Trav {
-    V3 inv;      // Ray ctor: rcp(direction) (src/ray.h:18)
-    V3 oi;       // origin * inv: slab distance = fma(bound, inv, -oi)
+    V3 inv;      // rcp(direction) (src/ray.h:18) expressed in the BVH frame: 1 / (d * frame_s)
+    V3 oi;       // (origin - frame_c) * rcp(direction): slab distance = fma(bound', inv, -oi)
     int node;    // >= 0: inner-node record; < -1: leaf link ~((first << 4) | count); -1: nothing to traverse
     int sp;      // stack entries in use; < 0 <=> traversal finished
     Hit hit;
 };
 DEVFN bool trav_active(const Trav& tv) { return tv.sp >= 0; }
 
-DEVFN void trav_begin(Trav& tv, V3 o, V3 d) {
+DEVFN void trav_begin(const DevScene& sc, Trav& tv, V3 o, V3 d) {
+#ifdef TRH_NODE32
     tv.inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
     tv.oi = o * tv.inv;
+#else
+    // The fp16 bounds live in the frame x' = (x - c) * s with s a power of two, so
+    // t = (x - o) / d = x' * (1 / (d s)) - (o - c) * (1 / d): one fma per plane, as before.
+    // |1/d| is clamped so that the product with 1/s stays finite (only matters for s < 1, i.e. scenes
+    // larger than +-32768 units): a direction change of < 1e-36, far inside the box padding.
+    // v_rcp_f32 (1 ulp) instead of the IEEE division of Ray's ctor: these reciprocals only feed the
+    // conservative box tests (relative slab error 1e-7 against a 1e-5 padding); Moller-Trumbore uses d.
+    const float lim = sc.frame_inv_lim;
+    const V3 inv = mk(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -lim, lim), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -lim, lim),
+                      __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -lim, lim));
+    tv.oi = mk((o.x - sc.frame_c[0]) * inv.x, (o.y - sc.frame_c[1]) * inv.y, (o.z - sc.frame_c[2]) * inv.z);
+    tv.inv = inv * sc.frame_sinv;
+#endif
     tv.hit.t = 3.402823466e+38f;  // HitData.t = FLT_MAX (cpu_trace.cpp:119)
     tv.hit.u = tv.hit.v = 0.f;
     tv.hit.prim = -1;
@@ -162,10 +178,24 @@ DEVFN void trav_pop(Trav& tv, const int* __restrict__ stack) {
 // one inner-node record: one 64-byte fetch, two slab tests. Precondition: tv.node >= 0.
 template <bool STATS>
 DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stack, Counters& cnt) {
+#ifdef TRH_NODE32
     const float4 n0 = sc.nodes[tv.node * 4 + 0];
     const float4 n1 = sc.nodes[tv.node * 4 + 1];
     const float4 nz = sc.nodes[tv.node * 4 + 2];
     const float4 lk = sc.nodes[tv.node * 4 + 3];
+    const int c0 = __float_as_int(lk.x), c1 = __float_as_int(lk.y);
+#else
+    // 32-byte record: two 16-byte loads; the fp16 -> fp32 conversion is free (v_fma_mix_f32 reads either half)
+    const uint4 qa = sc.nodes16[tv.node * 2 + 0];
+    const uint4 qb = sc.nodes16[tv.node * 2 + 1];
+    const H2 hx0 = __builtin_bit_cast(H2, qa.x), hy0 = __builtin_bit_cast(H2, qa.y);
+    const H2 hx1 = __builtin_bit_cast(H2, qa.z), hy1 = __builtin_bit_cast(H2, qa.w);
+    const H2 hz0 = __builtin_bit_cast(H2, qb.x), hz1 = __builtin_bit_cast(H2, qb.y);
+    struct { float x, y, z, w; } n0 = {(float)hx0.x, (float)hx0.y, (float)hy0.x, (float)hy0.y},
+                                 n1 = {(float)hx1.x, (float)hx1.y, (float)hy1.x, (float)hy1.y},
+                                 nz = {(float)hz0.x, (float)hz0.y, (float)hz1.x, (float)hz1.y};
+    const int c0 = (int)qb.z, c1 = (int)qb.w;
+#endif
     if (STATS) { cnt.box_tests += 2; if (first_active_lane()) cnt.w_inner += 1; }
 #ifdef TRH_EXP_DUP_LOADS   // perturbation experiment: fetch a second (different) record and keep it alive
     {
@@ -199,7 +229,6 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
 #endif
     const bool h0 = tmin0 <= tmax0;
     const bool h1 = tmin1 <= tmax1;
-    const int c0 = __float_as_int(lk.x), c1 = __float_as_int(lk.y);
     const bool swp = h1 && (!h0 || tmin1 < tmin0);   // child 1 is the nearer (or the only) hit
     const int nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
     stack[tv.sp * TRH_BLOCK] = farc;   // unconditional: slot sp is free; it only counts if both were hit
@@ -238,7 +267,7 @@ DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__
         if (ok) {
             const float rdet = 1.f / det;
             const float t = dot_f(e2, qvec) * rdet;
-            if (accept_candidate(sc, o, tv.inv, t, id, tv.hit)) {
+            if (accept_candidate(sc, o, d, t, id, tv.hit)) {
                 tv.hit.t = t;
                 tv.hit.u = u * rdet;
                 tv.hit.v = v * rdet;
@@ -258,7 +287,7 @@ DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__
 template <bool STATS>
 DEVFN void intersect(const DevScene& sc, V3 o, V3 d, Hit& hit, int* __restrict__ stack, Counters& cnt) {
     Trav tv;
-    trav_begin(tv, o, d);
+    trav_begin(sc, tv, o, d);
     while (trav_active(tv)) {
         while (tv.node >= 0) trav_inner<STATS>(sc, o, tv, stack, cnt);
         if (trav_active(tv)) trav_leaf<STATS>(sc, o, d, tv, stack, cnt);

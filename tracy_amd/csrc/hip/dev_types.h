@@ -29,7 +29,8 @@ struct DevTexture {
 
 // Everything a kernel needs, passed by value as a kernel argument.
 struct DevScene {
-    const float4* nodes;       // 4 float4 per inner-node record (see bvh_builder.h)
+    const float4* nodes;       // 4 float4 per fp32 inner-node record (see bvh_builder.h); only with -DTRH_NODE32
+    const uint4* nodes16;      // 2 uint4 per compact record: fp16 bounds in the BVH frame + 2 child links
     const float4* tris;        // 3 float4 per primitive, leaf order: (v0, id) (e1, 0) (e2, 0)
     const float4* shade;       // 4 float4 per primitive: n0 n1 n2 (9) uv0 uv1 uv2 (6) material (1)
     const float4* tangents;    // 3 float4 per primitive (t0 t1 t2), NULL if no normal map is used
@@ -41,6 +42,9 @@ struct DevScene {
     uint32_t flags;
     float eye[3];
     float ivp[16];             // column-major inverse(projection * view)
+    float frame_c[3];          // BVH frame: x' = (x - frame_c) * frame_s, frame_s a power of two
+    float frame_sinv;          // 1 / frame_s
+    float frame_inv_lim;       // largest |1/d| whose product with frame_sinv stays finite
 };
 
 struct RenderParams {

@@ -180,7 +180,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             if (has_path && !trav_active(tv)) {
                 const bool cont = shade<STATS>(sc, ps, tv.hit, cnt);
                 if (cont) {
-                    trav_begin(tv, ps.o, ps.d);
+                    trav_begin(sc, tv, ps.o, ps.d);
                 } else {
                     __hip_atomic_fetch_add(&wacc[pix * 3 + 0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&wacc[pix * 3 + 1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -203,7 +203,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                         if (px < sc.width && py < sc.height) {
                             if (STATS) { cnt.l_gen += 1; if (first_active_lane()) cnt.w_gen += 1; }
                             generate(sc, ps, px, py, sample, rp.seed32);
-                            trav_begin(tv, ps.o, ps.d);
+                            trav_begin(sc, tv, ps.o, ps.d);
                             has_path = true;
                         }   // else: pixel outside the frame (partial edge tile): the item is dropped
                     } else {
@@ -704,6 +704,12 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     int rc;
     if ((rc = dev_alloc_copy(c, r.nodes.data(), r.nodes.size(), &dp))) return rc;
     sc.nodes = (const float4*)dp;
+    uint32_t* dq = nullptr;
+    if ((rc = dev_alloc_copy(c, r.nodes16.data(), r.nodes16.size(), &dq))) return rc;
+    sc.nodes16 = (const uint4*)dq;
+    memcpy(sc.frame_c, r.frame_center, 12);
+    sc.frame_sinv = 1.f / r.frame_scale;
+    sc.frame_inv_lim = r.frame_scale < 1.f ? 3.0e38f * r.frame_scale : 3.402823466e+38f;
     if ((rc = dev_alloc_copy(c, r.tris.data(), r.tris.size(), &dp))) return rc;
     sc.tris = (const float4*)dp;
     if ((rc = dev_alloc_copy(c, shade.data(), shade.size(), &dp))) return rc;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers 
                     const float4 a = wf.st[slot * 5u + 0u], b = wf.st[slot * 5u + 1u];
                     o = mk(a.x, a.y, a.z);
                     d = mk(b.x, b.y, b.z);
-                    trav_begin(tv, o, d);
+                    trav_begin(sc, tv, o, d);
                     has_ray = true;
                 } else if (queue_empty) {
                     drained = true;

@@ -35,6 +35,57 @@ struct Ref {
 float kCostTraverse = 0.5f;   // one inner-record step (two slab tests)
 constexpr float kCostIntersect = 1.0f;   // one Moller-Trumbore test
 
+// ---- IEEE binary16 with directed rounding (host only; g++ 11 has no _Float16 on x86)
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp((float)(m | 1024u), (int)e - 25);
+    return sign ? -v : v;
+}
+uint16_t half_next_down(uint16_t h) {   // next representable value toward -inf (h finite or +inf)
+    if (h == 0x0000u) return 0x8001u;
+    return (h & 0x8000u) ? (uint16_t)(h + 1u) : (uint16_t)(h - 1u);
+}
+uint16_t half_next_up(uint16_t h) {     // toward +inf (h finite or -inf)
+    if (h == 0x8000u) return 0x0001u;
+    return (h & 0x8000u) ? (uint16_t)(h - 1u) : (uint16_t)(h + 1u);
+}
+uint16_t half_nearest(double v) {       // any rounding will do: the callers fix the direction afterwards
+    if (!(v == v)) return 0x7E00u;
+    const uint16_t sign = std::signbit(v) ? 0x8000u : 0u;
+    double a = std::fabs(v);
+    if (a >= 65520.0) return sign | 0x7C00u;
+    if (a < std::ldexp(1.0, -25)) return sign;
+    int ex;
+    (void)std::frexp(a, &ex);           // a = f * 2^ex, f in [0.5, 1)
+    int e = ex - 1 + 15;                // biased exponent of the leading bit
+    if (e <= 0) {                       // subnormal: units of 2^-24
+        const uint32_t q = (uint32_t)std::lround(std::ldexp(a, 24));
+        return sign | (uint16_t)q;      // q == 1024 rolls over into the smallest normal, as it should
+    }
+    uint32_t q = (uint32_t)std::lround(std::ldexp(a, 10 - (ex - 1)));  // in [1024, 2048]
+    if (q == 2048u) { q = 1024u; ++e; }
+    if (e >= 31) return sign | 0x7C00u;
+    return sign | (uint16_t)((uint32_t)e << 10) | (uint16_t)(q - 1024u);
+}
+uint16_t half_floor(double v) {         // largest half <= v (v > -65504 assumed; -inf otherwise)
+    if (v >= 65504.0) return 0x7BFFu;
+    if (v < -65504.0) return 0xFC00u;
+    uint16_t h = half_nearest(v);
+    while ((double)half_to_float(h) > v) h = half_next_down(h);
+    return h;
+}
+uint16_t half_ceil(double v) {          // smallest half >= v
+    if (v <= -65504.0) return 0xFBFFu;
+    if (v > 65504.0) return 0x7C00u;
+    uint16_t h = half_nearest(v);
+    while ((double)half_to_float(h) < v) h = half_next_up(h);
+    return h;
+}
+
 int levels_needed(size_t n) {  // inner-record levels a median-split subtree of n prims needs
     int l = 0;
     while (n > (size_t)kMaxLeafSize) { n = (n + 1) / 2; ++l; }
@@ -179,6 +230,55 @@ struct Builder {
         r[15] = 0.f;
     }
 
+    // 32-byte records from the finished fp32 records (layout in bvh_builder.h)
+    void quantise() {
+        // frame: centre = per-axis median of the centroids, scale = the power of two that maps the
+        // farthest padded bound to [16384, 32768)
+        double c[3] = {0, 0, 0};
+        if (!refs.empty()) {
+            std::vector<float> tmp(refs.size());
+            for (int a = 0; a < 3; ++a) {
+                for (size_t i = 0; i < refs.size(); ++i) tmp[i] = refs[i].c[a];
+                std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+                c[a] = tmp[tmp.size() / 2];
+            }
+        }
+        double far = 0.0;
+        const size_t n = out.nodes.size() / 16;
+        for (size_t i = 0; i < n; ++i) {
+            const float* r = &out.nodes[i * 16];
+            const int axis_of[12] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 2, 2};
+            for (int k = 0; k < 12; ++k)
+                if (std::fabs(r[k]) < 1e30f) far = std::max(far, std::fabs((double)r[k] - c[axis_of[k]]));
+        }
+        int k2 = 0;
+        if (far > 0.0) {
+            int ex;
+            (void)std::frexp(far, &ex);       // far in [2^(ex-1), 2^ex)
+            k2 = 15 - ex;                     // far * 2^k2 in [16384, 32768)
+        }
+        k2 = std::min(60, std::max(-60, k2));
+        const double s = std::ldexp(1.0, k2);
+        for (int a = 0; a < 3; ++a) out.frame_center[a] = (float)c[a];
+        out.frame_scale = (float)s;
+        out.nodes16.assign(n * 8, 0u);
+        for (size_t i = 0; i < n; ++i) {
+            const float* r = &out.nodes[i * 16];
+            uint32_t* q = &out.nodes16[i * 8];
+            auto pack = [&](float mn, float mx, int axis) {
+                const double cc = (double)out.frame_center[axis];   // the float the kernel subtracts
+                const uint16_t lo = half_floor(((double)mn - cc) * s);
+                const uint16_t hi = half_ceil(((double)mx - cc) * s);
+                return (uint32_t)lo | ((uint32_t)hi << 16);
+            };
+            q[0] = pack(r[0], r[1], 0);  q[1] = pack(r[2], r[3], 1);
+            q[2] = pack(r[4], r[5], 0);  q[3] = pack(r[6], r[7], 1);
+            q[4] = pack(r[8], r[9], 2);  q[5] = pack(r[10], r[11], 2);
+            memcpy(&q[6], &r[12], 4);
+            memcpy(&q[7], &r[13], 4);
+        }
+    }
+
     void run() {
         refs.resize(in.size());
         Box all;
@@ -225,6 +325,7 @@ void build(const std::vector<InputTriangle>& tris, Result& out) {
     if (const char* e = getenv("TRH_SAH_CT")) { const float v = (float)atof(e); if (v > 0.f) kCostTraverse = v; }   // development knob
     Builder b(tris, out);
     b.run();
+    b.quantise();
 }
 
 }  // namespace bvh

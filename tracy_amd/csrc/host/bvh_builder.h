@@ -29,8 +29,21 @@ struct InputTriangle {
 //   [12..15] child0 child1 (int bits) 0 0
 // child >= 0: index of an inner-node record; child < -1: leaf, ~child = (first_prim << 4) | count
 // (count may be 0 for the padding leaf of tiny scenes; the value -1 is never produced)
+//
+// Compact form of the same record, 32 bytes (8 x u32), the one the kernels traverse: bounds as IEEE
+// half floats in the FRAME x' = (x - frame_center) * frame_scale (frame_scale a power of two, the
+// centre = per-axis median of the triangle centroids so that fp16 is finest where the geometry is
+// dense), minima rounded toward -inf and maxima toward +inf AFTER the padding above, so a quantised
+// box always contains the fp32 box:
+//   [0] c0.min.x | c0.max.x << 16   [1] c0.min.y | c0.max.y << 16
+//   [2] c1.min.x | c1.max.x << 16   [3] c1.min.y | c1.max.y << 16
+//   [4] c0.min.z | c0.max.z << 16   [5] c1.min.z | c1.max.z << 16
+//   [6] child0                      [7] child1
 struct Result {
     std::vector<float> nodes;          // 16 floats per inner node, node 0 is the root
+    std::vector<uint32_t> nodes16;     // 8 words per inner node, same order
+    float frame_center[3] = {0.f, 0.f, 0.f};
+    float frame_scale = 1.f;           // power of two
     std::vector<float> tris;           // 12 floats per primitive in leaf order: v0.xyz id | e1.xyz 0 | e2.xyz 0
     std::vector<uint32_t> prim_index;  // leaf-order position -> index into the input triangle array
     uint32_t max_depth = 0;
