@@ -779,7 +779,7 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     c->bvh.tri_count = (uint32_t)nprim;
     c->bvh.max_depth = r.max_depth;
     c->bvh.max_leaf_size = r.max_leaf;
-    c->bvh.node_bytes = r.nodes.size() * 4;
+    c->bvh.node_bytes = r.nodes16.size() * 4;   // the 32-byte records the kernels traverse
     c->bvh.tri_bytes = r.tris.size() * 4;
     c->bvh.sah_cost = r.sah_cost;
     c->bvh.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
