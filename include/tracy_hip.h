@@ -173,6 +173,23 @@ int trh_bind_accum_buffer(trh_context* ctx, void* dptr, size_t nbytes);
  * accumulated since the last reset (as counted by this context). */
 int trh_resolve(trh_context* ctx, float* rgba_host, uint64_t* samples_out);
 
+/* Display-side post, replaces CPUDetails::Tonemap + UpdateBitmap + Bitmap::SetPixel
+ * (cpu_details.cpp:201-243, bitmap.cpp:58-69) for the whole frame on the device:
+ * mean = sum / count, colour * exposure, tone curve, srgb(), clamp(255.99 * c, 0, 255), u8
+ * truncation, packed as 0x00RRGGBB (bytes B,G,R,0 -- the XImage/DIB layout of bitmap.cpp:28-39).
+ * Output row 0 is the TOP row of the picture (the reference flips in SetPixel; it writes row
+ * `height - y`, one past the end for y = 0 -- this call uses the evident intent height-1-y).
+ * tonemap selects the reference's compile-time variants (CMakeLists.txt:92-103):
+ * sRGB (default build), Reinhard, ACES (curves as spelled out in cuda_details.cpp:36-41), or none.
+ * bgra_host: width*height uint32, may be NULL (the device image is still produced). */
+typedef enum trh_tonemap {
+    TRH_TONEMAP_NONE = 0,
+    TRH_TONEMAP_SRGB = 1,
+    TRH_TONEMAP_REINHARD = 2,
+    TRH_TONEMAP_ACES = 3
+} trh_tonemap;
+int trh_present_bgra8(trh_context* ctx, int tonemap /* trh_tonemap */, float exposure, uint32_t* bgra_host);
+
 /* Parity probe (a): nearest hit of the un-jittered primary ray through each pixel centre
  * ((x+.5)/W, (y+.5)/H). ids[p] = (mesh << 24) | triangle (cpu_details.h:34), 0xffffffff on
  * miss. t and uv (2 floats per pixel: Moller-Trumbore u,v) are optional (may be NULL). */

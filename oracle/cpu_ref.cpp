@@ -793,6 +793,34 @@ int oref_ray_aabb(const float o[3], const float d[3], const float bmin[3], const
     Ray r(vec3(o[0], o[1], o[2]), vec3(d[0], d[1], d[2]));
     return RayAABB(r.origin, r.inv_direction, vec3(bmin[0], bmin[1], bmin[2]), vec3(bmax[0], bmax[1], bmax[2]), tmax) ? 1 : 0;
 }
+// CPUDetails::Tonemap + Bitmap::SetPixel (cpu_details.cpp:218-243, bitmap.cpp:58-69) on a linear
+// RGB image whose row 0 is the bottom row (the module's output[]): out row 0 is the top row,
+// pixels 0x00RRGGBB. mode: 0 none, 1 sRGB, 2 Reinhard, 3 ACES (curves: cuda_details.cpp:36-41;
+// srgb = glm convertLinearToSRGB, the in-tree stand-in for cclib's, common.h:152).
+void oref_tonemap_bgra8(const float* rgb, uint32_t w, uint32_t h, int mode, float exposure, uint32_t* out) {
+    auto srgb = [](float c) {
+        c = std::min(std::max(c, 0.f), 1.f);
+        return c < 0.0031308f ? c * 12.92f : std::pow(c, 0.41666f) * 1.055f - 0.055f;
+    };
+    auto curve = [mode](float x) {
+        if (mode == 2) return std::min(std::max(x / (1.f + x), 0.f), 1.f);
+        if (mode == 3) return std::min(std::max((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.f), 1.f);
+        return x;
+    };
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            const float* p = rgb + ((size_t)y * w + x) * 3;
+            uint32_t b[3];
+            for (int k = 0; k < 3; ++k) {
+                float v = p[k] * exposure;
+                if (mode != 0) v = srgb(curve(v));
+                v = std::min(std::max(255.99f * v, 0.f), 255.f);
+                b[k] = (uint32_t)(uint8_t)v;
+            }
+            out[(size_t)(h - 1 - y) * w + x] = b[2] | (b[1] << 8) | (b[0] << 16);
+        }
+}
+
 int oref_num_threads(void) {
 #if defined(_OPENMP)
     return omp_get_max_threads();

@@ -37,8 +37,18 @@ def lib():
         L.oref_ray_triangle.argtypes = [C.c_void_p] * 5 + [C.POINTER(C.c_float), C.c_void_p]
         L.oref_ray_aabb.argtypes = [C.c_void_p] * 4 + [C.c_float]
         L.oref_num_threads.restype = C.c_int
+        L.oref_tonemap_bgra8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_void_p]
         _lib = L
     return _lib
+
+
+def tonemap_bgra8(rgb, mode=1, exposure=1.0):
+    """CPUDetails::Tonemap + Bitmap::SetPixel on an (H, W, 3) linear image (row 0 = bottom)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[:2]
+    out = np.empty((h, w), dtype=np.uint32)
+    lib().oref_tonemap_bgra8(rgb.ctypes.data, w, h, mode, exposure, out.ctypes.data)
+    return out
 
 
 class CpuRef:

@@ -48,3 +48,29 @@ def test_cli_renders_like_the_python_host(tmp_path):
     ref, _ = mod.resolve()
     mod.Shutdown()
     assert np.array_equal(img, ref[..., :3])
+
+
+@pytest.mark.gpu
+def test_cli_writes_the_tonemapped_picture_as_png_and_ppm(tmp_path):
+    """-out x.png / x.ppm hold the module's own picture (trh_present_bgra8); the PNG must decode
+    (PIL checks the chunk CRCs and the zlib adler32) to the same pixels as the PPM and as the
+    Python host's present() of the same samples."""
+    from PIL import Image
+    from tracy_amd import Scene, HipTrace, capi
+    common = [CLI, "-scene", os.path.join(ROOT, "assets/data/scenes/spheres.scn"), "-assets", os.path.join(ROOT, "assets"),
+              "-kernel", "hip", "-width", "96", "-height", "54", "-spp", "8", "-spu", "8", "-tonemap", "aces", "-exposure", "1.25"]
+    png, ppm = str(tmp_path / "a.png"), str(tmp_path / "a.ppm")
+    for out in (png, ppm):
+        r = subprocess.run(common + ["-out", out], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    a = np.asarray(Image.open(png).convert("RGB"))
+    b = np.asarray(Image.open(ppm).convert("RGB"))
+    assert a.shape == (54, 96, 3) and np.array_equal(a, b)
+    sc = Scene("data/scenes/spheres.scn", 96, 54)
+    mod = HipTrace()
+    mod.Startup(sc)
+    mod.render(0, 8)
+    pic = mod.present(tonemap=capi.TRH_TONEMAP_ACES, exposure=1.25)
+    mod.Shutdown()
+    rgb = np.stack([(pic >> 16) & 255, (pic >> 8) & 255, pic & 255], axis=-1).astype(np.uint8)
+    assert np.array_equal(a, rgb)

@@ -17,6 +17,7 @@ TRH_FLAG_RUSSIAN_ROULETTE = 1
 TRH_PIPELINE_MEGAKERNEL = 0
 TRH_PIPELINE_WAVEFRONT = 1
 TRH_PIPELINE_MEGAKERNEL_SIMPLE = 2
+TRH_TONEMAP_NONE, TRH_TONEMAP_SRGB, TRH_TONEMAP_REINHARD, TRH_TONEMAP_ACES = 0, 1, 2, 3
 
 
 class trh_material(C.Structure):
@@ -95,6 +96,7 @@ HIP_SYMBOLS = {
     "trh_accum_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "trh_bind_accum_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "trh_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "trh_present_bgra8": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "trh_primary_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trh_sample_radiance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]),
     "trh_get_stats": (C.c_int, [C.c_void_p, C.POINTER(trh_stats), C.c_int]),

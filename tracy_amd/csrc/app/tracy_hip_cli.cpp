@@ -3,7 +3,10 @@
 // (Startup -> [OnEvent]* -> OnUpdate -> OnRender -> GetRayCount(true) -> Shutdown), same statistics
 // text ("[%.2f MRays/s @ %.2f fps]", win_raytracer.cpp:532,566). No window: the GPU box has no X
 // server. Extra flags: -width/-height (override OUT), -spp N (stop after N samples per pixel),
-// -spu K (samples per OnUpdate), -out file.pfm|file.ppm, -device D.
+// -spu K (samples per OnUpdate), -out file.pfm (linear) | file.ppm | file.png (tonemapped picture),
+// -tonemap srgb|reinhard|aces|none and -exposure E (the reference's TRACY_TONEMAPPING / TRACY_EXPOSURE
+// build options, CMakeLists.txt:92-103), -device D.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -24,23 +27,72 @@ static bool WritePFM(const char* path, const float* rgba, uint32_t w, uint32_t h
     return true;
 }
 
-// CPUDetails::Tonemap, sRGB variant (cpu_details.cpp:218-243) + Bitmap::SetPixel's Y flip (bitmap.cpp:58-69)
-static bool WritePPM(const char* path, const float* rgba, uint32_t w, uint32_t h) {
+// the module's own picture (trh_present_bgra8: CPUDetails::Tonemap + Bitmap::SetPixel), 0x00RRGGBB, top row first
+static bool WritePPM(const char* path, const uint32_t* bgra, uint32_t w, uint32_t h) {
     FILE* f = fopen(path, "wb");
     if (!f) return false;
     fprintf(f, "P6\n%u %u\n255\n", w, h);
-    for (uint32_t y = 0; y < h; ++y)
-        for (uint32_t x = 0; x < w; ++x) {
-            const float* p = rgba + ((size_t)(h - 1 - y) * w + x) * 4;
-            unsigned char o[3];
-            for (int k = 0; k < 3; ++k) {
-                float c = p[k] * 1.0f;   // TRACY_EXPOSURE = 1
-                c = c <= 0.0031308f ? 12.92f * c : 1.055f * std::pow(c, 1.f / 2.4f) - 0.055f;
-                c = 255.99f * c;
-                o[k] = (unsigned char)(c < 0.f ? 0.f : (c > 255.f ? 255.f : c));
-            }
-            fwrite(o, 1, 3, f);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        const unsigned char o[3] = {(unsigned char)(bgra[i] >> 16), (unsigned char)(bgra[i] >> 8), (unsigned char)bgra[i]};
+        fwrite(o, 1, 3, f);
+    }
+    fclose(f);
+    return true;
+}
+
+// 8-bit RGB PNG with stored (uncompressed) deflate blocks: no zlib needed on the box
+static bool WritePNG(const char* path, const uint32_t* bgra, uint32_t w, uint32_t h) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return false;
+    static uint32_t crc_table[256];
+    if (!crc_table[1])
+        for (uint32_t n = 0; n < 256; ++n) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
         }
+    auto be32 = [](unsigned char* p, uint32_t v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; };
+    auto chunk = [&](const char* type, const std::string& data) {
+        unsigned char len[4], crc[4];
+        be32(len, (uint32_t)data.size());
+        uint32_t c = 0xffffffffu;
+        for (int i = 0; i < 4; ++i) c = crc_table[(c ^ (unsigned char)type[i]) & 255u] ^ (c >> 8);
+        for (unsigned char b : data) c = crc_table[(c ^ b) & 255u] ^ (c >> 8);
+        be32(crc, c ^ 0xffffffffu);
+        fwrite(len, 1, 4, f); fwrite(type, 1, 4, f); fwrite(data.data(), 1, data.size(), f); fwrite(crc, 1, 4, f);
+    };
+    fwrite("\x89PNG\r\n\x1a\n", 1, 8, f);
+    std::string ihdr(13, '\0');
+    be32((unsigned char*)&ihdr[0], w);
+    be32((unsigned char*)&ihdr[4], h);
+    ihdr[8] = 8; ihdr[9] = 2;   // 8 bits, colour type RGB
+    chunk("IHDR", ihdr);
+    std::string raw;
+    raw.reserve((size_t)h * (1 + 3 * (size_t)w));
+    for (uint32_t y = 0; y < h; ++y) {
+        raw.push_back('\0');   // filter: none
+        for (uint32_t x = 0; x < w; ++x) {
+            const uint32_t p = bgra[(size_t)y * w + x];
+            raw.push_back((char)(p >> 16)); raw.push_back((char)(p >> 8)); raw.push_back((char)p);
+        }
+    }
+    std::string z("\x78\x01", 2);
+    uint32_t a = 1, b = 0;
+    for (unsigned char c : raw) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        const bool last = off + n >= raw.size();
+        z.push_back(last ? 1 : 0);
+        z.push_back((char)(n & 255)); z.push_back((char)(n >> 8));
+        z.push_back((char)(~n & 255)); z.push_back((char)((~n >> 8) & 255));
+        z.append(raw, off, n);
+        if (last) break;
+    }
+    unsigned char ad[4];
+    be32(ad, (b << 16) | a);
+    z.append((const char*)ad, 4);
+    chunk("IDAT", z);
+    chunk("IEND", std::string());
     fclose(f);
     return true;
 }
@@ -49,7 +101,8 @@ int main(int argc, char** argv) {
     uint32_t WIDTH = 640, HEIGHT = 480;   // win_raytracer.cpp:439-440
     std::string scene_path = "data/default.scn", kernelname = "hip", out_path, asset_root = ".";
     uint32_t spp = 64, spu = 1;
-    int device = 0;
+    int device = 0, tonemap = TRH_TONEMAP_SRGB;
+    float exposure = 1.f;
     bool override_size = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a(argv[i]);
@@ -63,6 +116,11 @@ int main(int argc, char** argv) {
         else if (a == "-out") out_path = next("");
         else if (a == "-assets") asset_root = next(".");
         else if (a == "-device") device = atoi(next("0"));
+        else if (a == "-exposure") exposure = (float)atof(next("1"));
+        else if (a == "-tonemap") {
+            const std::string t = next("srgb");
+            tonemap = t == "none" ? TRH_TONEMAP_NONE : t == "reinhard" ? TRH_TONEMAP_REINHARD : t == "aces" ? TRH_TONEMAP_ACES : TRH_TONEMAP_SRGB;
+        }
     }
     if (kernelname != "hip" && kernelname != "HIP") {   // KernelNameToID (win_raytracer.cpp:48-56)
         fprintf(stderr, "Invalid kernel choice: should be one in [hip]\n");
@@ -77,6 +135,7 @@ int main(int argc, char** argv) {
     }
     handle_t win{WIDTH, HEIGHT};
     HipTrace kernel(device, spu);
+    kernel.SetTonemap(tonemap, exposure);
     if (!kernel.Startup(&win, world)) {
         fprintf(stderr, "Kernel failed to initialize\n");   // win_raytracer.cpp:572-575
         return EXIT_FAILURE;
@@ -110,8 +169,10 @@ int main(int argc, char** argv) {
     fprintf(stderr, "*** Performance: %.2f MRays/s and %.2f fps on average\n", rays_total * 1e-6 / trace_s, frames / trace_s);
     bool ok = true;
     if (!out_path.empty()) {
-        const bool ppm = out_path.size() > 4 && out_path.substr(out_path.size() - 4) == ".ppm";
-        ok = ppm ? WritePPM(out_path.c_str(), kernel.GetImage(), WIDTH, HEIGHT) : WritePFM(out_path.c_str(), kernel.GetImage(), WIDTH, HEIGHT);
+        const std::string ext = out_path.size() > 4 ? out_path.substr(out_path.size() - 4) : std::string();
+        ok = ext == ".ppm"   ? WritePPM(out_path.c_str(), kernel.GetBitmap(), WIDTH, HEIGHT)
+             : ext == ".png" ? WritePNG(out_path.c_str(), kernel.GetBitmap(), WIDTH, HEIGHT)
+                             : WritePFM(out_path.c_str(), kernel.GetImage(), WIDTH, HEIGHT);
         if (!ok) fprintf(stderr, "cannot write %s\n", out_path.c_str());
     }
     kernel.Shutdown();

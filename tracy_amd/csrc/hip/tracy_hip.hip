@@ -299,6 +299,34 @@ __global__ void k_resolve(const float4* __restrict__ accum, float4* __restrict__
     out[p] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w);
 }
 
+// CPUDetails::Tonemap + Bitmap::SetPixel for one pixel (cpu_details.cpp:218-243, bitmap.cpp:58-69)
+DEVFN float srgb_curve(float c) {   // glm convertLinearToSRGB (common.h:152): clamp, then the exact piece-wise curve
+    c = fminf(fmaxf(c, 0.f), 1.f);
+    return c < 0.0031308f ? c * 12.92f : powf(c, 0.41666f) * 1.055f - 0.055f;
+}
+DEVFN float tone_curve(float x, int mode) {
+    if (mode == TRH_TONEMAP_REINHARD) return fminf(fmaxf(x / (1.f + x), 0.f), 1.f);
+    if (mode == TRH_TONEMAP_ACES) return fminf(fmaxf((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.f), 1.f);
+    return x;
+}
+__global__ void k_present(const float4* __restrict__ accum, uint32_t* __restrict__ out, int width, int height, int mode, float exposure) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (uint32_t)(width * height)) return;
+    const int x = (int)(p % (uint32_t)width), y = (int)(p / (uint32_t)width);
+    const float4 a = accum[p];
+    const float inv = a.w > 0.f ? 1.f / a.w : 0.f;
+    float c[3] = {a.x * inv * exposure, a.y * inv * exposure, a.z * inv * exposure};
+    uint32_t b[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = c[k];
+        if (mode != TRH_TONEMAP_NONE) v = srgb_curve(tone_curve(v, mode));
+        v = fminf(fmaxf(255.99f * v, 0.f), 255.f);
+        b[k] = (uint32_t)v;   // (u8) truncation
+    }
+    out[(size_t)(height - 1 - y) * width + x] = b[2] | (b[1] << 8) | (b[0] << 16);
+}
+
 #include "wavefront.h"
 
 // =====================================================================================
@@ -344,6 +372,7 @@ struct trh_context {
     float4* accum = nullptr;          // buffer in use (internal or caller-bound)
     float4* accum_internal = nullptr;
     float4* resolved = nullptr;
+    uint32_t* bitmap = nullptr;       // BGRA8 picture of trh_present_bgra8
     DevCounters* counters = nullptr;
     unsigned int* tile_counter = nullptr;
     uint64_t samples = 0;        // since the last stats reset
@@ -386,6 +415,7 @@ int free_scene(trh_context* c) {
     c->accum = nullptr;
     c->accum_internal = nullptr;
     c->resolved = nullptr;
+    c->bitmap = nullptr;
     c->has_scene = false;
     return TRH_OK;
 }
@@ -770,6 +800,10 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     c->allocs.push_back(p);
     c->resolved = (float4*)p;
     HIP_TRY(hipMemset(p, 0, npix * sizeof(float4)));
+    HIP_TRY(hipMalloc(&p, npix * sizeof(uint32_t)));
+    c->allocs.push_back(p);
+    c->bitmap = (uint32_t*)p;
+    HIP_TRY(hipMemset(p, 0, npix * sizeof(uint32_t)));
 
     c->sc = sc;
     c->has_scene = true;
@@ -857,6 +891,19 @@ int trh_resolve(trh_context* c, float* rgba_host, uint64_t* samples_out) {
     if (rgba_host) HIP_TRY(hipMemcpyAsync(rgba_host, c->resolved, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (samples_out) *samples_out = c->accum_spp;
+    return TRH_OK;
+}
+
+int trh_present_bgra8(trh_context* c, int tonemap, float exposure, uint32_t* bgra_host) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_present_bgra8: ctx is NULL");
+    if (!c->has_scene) return fail(TRH_ERR_STATE, "trh_present_bgra8: no scene");
+    if (tonemap < TRH_TONEMAP_NONE || tonemap > TRH_TONEMAP_ACES) return fail(TRH_ERR_INVALID_ARG, "trh_present_bgra8: unknown tonemap");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
+    hipLaunchKernelGGL(k_present, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, c->bitmap, c->sc.width, c->sc.height, tonemap, exposure);
+    HIP_TRY(hipGetLastError());
+    if (bgra_host) HIP_TRY(hipMemcpyAsync(bgra_host, c->bitmap, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return TRH_OK;
 }
 

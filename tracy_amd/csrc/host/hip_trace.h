@@ -155,6 +155,7 @@ public:
         width_ = flat.desc.width;
         height_ = flat.desc.height;
         image_.assign(static_cast<size_t>(width_) * height_ * 4, 0.f);
+        bitmap_.assign(static_cast<size_t>(width_) * height_, 0u);
         next_sample_ = 0;
         return true;
     }
@@ -178,12 +179,13 @@ public:
         next_sample_ += spp_per_update_;
     }
 
-    // The reference modules present into the window here (cpu_details.cpp:245-248). Headless: the
-    // linear mean image is resolved and kept for the caller (GetImage).
+    // The reference modules tonemap into their Bitmap and paint the window here
+    // (cpu_details.cpp:201-248). The picture is produced on the device by trh_present_bgra8
+    // (8 MB at 1080p instead of the 33 MB float image) and kept for the caller (GetBitmap); a
+    // host with a display blits it (XPutImage / StretchDIBits of bitmap.cpp:84-110).
     void OnRender(const WindowT in_Window) override {
         (void)in_Window;
-        uint64_t n = 0;
-        Check(trh_resolve(ctx_, image_.data(), &n), "trh_resolve");
+        Check(trh_present_bgra8(ctx_, tonemap_, exposure_, bitmap_.data()), "trh_present_bgra8");
     }
 
     void OnEvent(EventT in_Event, const WindowT in_Window, const SceneT& in_Scene) override {
@@ -206,7 +208,16 @@ public:
         return st.rays;
     }
 
-    const float* GetImage() const { return image_.data(); }   // width*height*4, row 0 = bottom row
+    // linear mean image (width*height*4 floats, row 0 = bottom row, .w = sample count), resolved on demand
+    const float* GetImage() {
+        uint64_t n = 0;
+        Check(trh_resolve(ctx_, image_.data(), &n), "trh_resolve");
+        return image_.data();
+    }
+    // picture of the last OnRender: width*height 0x00RRGGBB, row 0 = top row
+    const uint32_t* GetBitmap() const { return bitmap_.data(); }
+    // the reference fixes these at compile time (TRACY_TONEMAPPING / TRACY_EXPOSURE, CMakeLists.txt:92-103)
+    void SetTonemap(int in_Tonemap, float in_Exposure) { tonemap_ = in_Tonemap; exposure_ = in_Exposure; }
     uint32_t GetWidth() const { return width_; }
     uint32_t GetHeight() const { return height_; }
     uint32_t GetSampleCount() const { return next_sample_; }
@@ -234,6 +245,9 @@ private:
     uint32_t width_ = 0, height_ = 0, next_sample_ = 0;
     bool camera_dirty_ = false;
     std::vector<float> image_;
+    std::vector<uint32_t> bitmap_;
+    int tonemap_ = TRH_TONEMAP_SRGB;   // default build: USE_TONEMAP_SRGB, TRACY_EXPOSURE 1
+    float exposure_ = 1.f;
 };
 
 }  // namespace tracy_hip

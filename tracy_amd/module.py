@@ -121,6 +121,12 @@ class HipTrace:
         self._check(self._lib.trh_resolve(self._ctx, None, C.byref(n)))
         return None, n.value
 
+    def present(self, tonemap=capi.TRH_TONEMAP_SRGB, exposure=1.0):
+        """Tonemapped 0x00RRGGBB picture, row 0 = top (CPUDetails::UpdateBitmap, cpu_details.cpp:201-243)."""
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        self._check(self._lib.trh_present_bgra8(self._ctx, tonemap, exposure, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def primary_hits(self):
         ids = np.empty((self.height, self.width), dtype=np.uint32)
         t = np.empty((self.height, self.width), dtype=np.float32)
