@@ -68,6 +68,18 @@ int tsc_set_texture_f32(tsc_scene* s, uint32_t i, uint32_t w, uint32_t h, const 
 /* Deterministic stand-in for the missing data/sky.hdr (formula: BASELINE.md section 3). */
 int tsc_set_texture_synthetic_sky(tsc_scene* s, uint32_t i);
 
+/* Texture file decoding without stb_image / PIL (replaces the stbi_load / stbi_loadf calls of
+ * Scene::Init, src/scene.cpp:23-48, for hosts outside the Tracy tree): decodes every texture that
+ * has no pixels yet from `asset_root`/<path> with the built-in decoders -- baseline JPEG
+ * (RGBA8, grey replicated, alpha 255, as stbi_load(.., 4)) and Radiance RGBE .hdr (as stbi_loadf).
+ * A missing .hdr becomes the synthetic sky if synthetic_missing_hdr != 0 (the reference's
+ * data/sky.hdr is not shipped). Any other missing / undecodable file is an error. */
+int tsc_decode_textures(tsc_scene* s, int synthetic_missing_hdr);
+/* The decoders on their own (tests, tools). *_out buffers are malloc'ed; release with tsc_free_pixels. */
+int tsc_decode_jpeg_file(const char* path, uint32_t* w_out, uint32_t* h_out, uint8_t** rgba8_out);
+int tsc_decode_hdr_file(const char* path, uint32_t* w_out, uint32_t* h_out, float** rgba_out);
+void tsc_free_pixels(void* p);
+
 /* Fills a trh_scene_desc whose pointers stay valid until tsc_free / the next tsc_set_*.
  * Fails if a referenced texture has no pixels yet. */
 int tsc_fill_desc(const tsc_scene* s, trh_scene_desc* out);

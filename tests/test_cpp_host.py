@@ -74,3 +74,27 @@ def test_cli_writes_the_tonemapped_picture_as_png_and_ppm(tmp_path):
     mod.Shutdown()
     rgb = np.stack([(pic >> 16) & 255, (pic >> 8) & 255, pic & 255], axis=-1).astype(np.uint8)
     assert np.array_equal(a, rgb)
+
+
+@pytest.mark.gpu
+def test_cli_renders_the_textured_helmet_with_the_builtin_decoders(tmp_path):
+    """helmet.scn needs five JPEG maps and (missing) sky.hdr: the C++ host decodes them itself and
+    must produce exactly the image of the Python host, which takes the same decoders."""
+    out = str(tmp_path / "helmet.pfm")
+    r = subprocess.run([CLI, "-scene", os.path.join(ROOT, "assets/data/scenes/helmet.scn"), "-assets", os.path.join(ROOT, "assets"),
+                        "-kernel", "hip", "-width", "96", "-height", "54", "-spp", "4", "-spu", "4", "-out", out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with open(out, "rb") as f:
+        assert f.readline() == b"PF\n"
+        w, h = map(int, f.readline().split())
+        f.readline()
+        img = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+    from tracy_amd import Scene, HipTrace
+    sc = Scene("data/scenes/helmet.scn", 96, 54)
+    mod = HipTrace()
+    mod.Startup(sc)
+    mod.render(0, 4)
+    ref, _ = mod.resolve()
+    mod.Shutdown()
+    assert np.array_equal(img, ref[..., :3])

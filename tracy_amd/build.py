@@ -48,7 +48,7 @@ def build_scene(force=False):
     if force or _stale(out, deps):
         os.makedirs(LIB, exist_ok=True)
         _run(["g++", *HOST_FLAGS, "-shared", "-I", os.path.join(ROOT, "include"),
-              os.path.join(HERE, "csrc", "host", "scene_host.cpp"), "-o", out])
+              os.path.join(HERE, "csrc", "host", "scene_host.cpp"), os.path.join(HERE, "csrc", "host", "image_decode.cpp"), "-o", out])
     return out
 
 

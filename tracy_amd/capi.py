@@ -76,6 +76,10 @@ SCENE_SYMBOLS = {
     "tsc_set_texture_u8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "tsc_set_texture_f32": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "tsc_set_texture_synthetic_sky": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "tsc_decode_textures": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsc_decode_jpeg_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8))]),
+    "tsc_decode_hdr_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]),
+    "tsc_free_pixels": (None, [C.c_void_p]),
     "tsc_fill_desc": (C.c_int, [C.c_void_p, C.POINTER(trh_scene_desc)]),
 }
 

@@ -20,17 +20,9 @@ public:
     bool Init(const char* scene_path, const char* asset_root, uint32_t& inout_width, uint32_t& inout_height, bool override_size) {
         h_ = tsc_load(scene_path, asset_root, override_size ? (int)inout_width : 0, override_size ? (int)inout_height : 0);
         if (!h_) { error_ = tsc_last_error(); return false; }
-        for (uint32_t i = 0; i < tsc_texture_count(h_); ++i) {
-            tsc_texture_info info{};
-            tsc_get_texture_info(h_, i, &info);
-            if (info.is_hdr) {
-                // data/sky.hdr is not shipped with the reference (.MISSING_LARGE_BLOBS): documented synthetic probe
-                if (tsc_set_texture_synthetic_sky(h_, i) != TRH_OK) { error_ = tsc_last_error(); return false; }
-            } else {
-                error_ = std::string("texture '") + info.path + "' needs an image decoder (stb_image inside Tracy, PIL in the Python host)";
-                return false;
-            }
-        }
+        // stbi_load / stbi_loadf of Scene::Init (src/scene.cpp:23-48): built-in JPEG and Radiance-HDR decoders;
+        // data/sky.hdr is not shipped with the reference (.MISSING_LARGE_BLOBS): documented synthetic probe
+        if (tsc_decode_textures(h_, 1) != TRH_OK) { error_ = tsc_last_error(); return false; }
         if (tsc_fill_desc(h_, &desc_) != TRH_OK) { error_ = tsc_last_error(); return false; }
         inout_width = desc_.width;
         inout_height = desc_.height;

@@ -5,6 +5,7 @@
 // Geometry produced here decides hit ids, so the reference's quirks are kept on purpose
 // (per-quad unshared sphere vertices, position-only OBJ vertex dedupe, "last triangle wins"
 // flat normals, the += / = tangent accumulation, Transform applied even for identity).
+#include "image_decode.h"
 #include "tracy_scene.h"
 #include "hmath.h"
 
@@ -110,6 +111,7 @@ struct TextureSlot {
 
 struct tsc_scene {
     std::string name;
+    std::string asset_root;
     uint32_t width = 0, height = 0;
     tsc_camera cam{};
     std::vector<Mesh> objects;
@@ -354,6 +356,7 @@ tsc_scene* tsc_load(const char* scn_path, const char* asset_root, int override_w
     if (!fp) { set_err(std::string("tsc_load: cannot open ") + scn_path); return nullptr; }
 
     auto* s = new tsc_scene();
+    s->asset_root = root;
     s->materials.push_back(make_material());  // materials_{1}: default sky (src/scene.h:67)
     // main() defaults (src/win_raytracer.cpp:439-440), overridden by OUT
     uint32_t width = 640, height = 480;
@@ -631,6 +634,73 @@ int tsc_set_texture_synthetic_sky(tsc_scene* s, uint32_t i) {
     t.srgb = srgb;
     return rc;
 }
+
+int tsc_decode_textures(tsc_scene* s, int synthetic_missing_hdr) {
+    if (!s) { set_err("tsc_decode_textures: NULL scene"); return TRH_ERR_INVALID_ARG; }
+    for (uint32_t i = 0; i < s->textures.size(); ++i) {
+        TextureSlot& t = s->textures[i];
+        if (!t.rgba.empty()) continue;
+        const std::string full = join_path(s->asset_root, t.path);
+        std::vector<uint8_t> bytes;
+        if (!imgdec::read_file(full, bytes)) {
+            if (t.is_hdr && synthetic_missing_hdr) {
+                int rc = tsc_set_texture_synthetic_sky(s, i);
+                if (rc) return rc;
+                continue;
+            }
+            set_err("tsc_decode_textures: cannot read '" + full + "'");
+            return TRH_ERR_INVALID_ARG;
+        }
+        std::string err;
+        int rc;
+        if (t.is_hdr) {
+            imgdec::ImageF img;
+            if (!imgdec::decode_hdr(bytes.data(), bytes.size(), img, err)) { set_err("tsc_decode_textures: '" + t.path + "': " + err); return TRH_ERR_INVALID_ARG; }
+            rc = tsc_set_texture_f32(s, i, img.width, img.height, img.rgba.data());
+        } else if (ends_with(t.path, ".jpg") || ends_with(t.path, ".jpeg")) {
+            imgdec::Image8 img;
+            if (!imgdec::decode_jpeg(bytes.data(), bytes.size(), img, err)) { set_err("tsc_decode_textures: '" + t.path + "': " + err); return TRH_ERR_INVALID_ARG; }
+            rc = tsc_set_texture_u8(s, i, img.width, img.height, img.rgba.data());
+        } else {
+            set_err("tsc_decode_textures: '" + t.path + "': no built-in decoder for this format (JPEG and Radiance HDR only); decode it and call tsc_set_texture_*");
+            return TRH_ERR_INVALID_ARG;
+        }
+        if (rc) return rc;
+    }
+    return TRH_OK;
+}
+
+int tsc_decode_jpeg_file(const char* path, uint32_t* w_out, uint32_t* h_out, uint8_t** rgba8_out) {
+    if (!path || !w_out || !h_out || !rgba8_out) { set_err("tsc_decode_jpeg_file: NULL argument"); return TRH_ERR_INVALID_ARG; }
+    std::vector<uint8_t> bytes;
+    if (!imgdec::read_file(path, bytes)) { set_err(std::string("tsc_decode_jpeg_file: cannot read ") + path); return TRH_ERR_INVALID_ARG; }
+    imgdec::Image8 img;
+    std::string err;
+    if (!imgdec::decode_jpeg(bytes.data(), bytes.size(), img, err)) { set_err("tsc_decode_jpeg_file: " + err); return TRH_ERR_INVALID_ARG; }
+    *rgba8_out = (uint8_t*)malloc(img.rgba.size());
+    if (!*rgba8_out) { set_err("tsc_decode_jpeg_file: out of memory"); return TRH_ERR_LIMIT; }
+    memcpy(*rgba8_out, img.rgba.data(), img.rgba.size());
+    *w_out = img.width;
+    *h_out = img.height;
+    return TRH_OK;
+}
+
+int tsc_decode_hdr_file(const char* path, uint32_t* w_out, uint32_t* h_out, float** rgba_out) {
+    if (!path || !w_out || !h_out || !rgba_out) { set_err("tsc_decode_hdr_file: NULL argument"); return TRH_ERR_INVALID_ARG; }
+    std::vector<uint8_t> bytes;
+    if (!imgdec::read_file(path, bytes)) { set_err(std::string("tsc_decode_hdr_file: cannot read ") + path); return TRH_ERR_INVALID_ARG; }
+    imgdec::ImageF img;
+    std::string err;
+    if (!imgdec::decode_hdr(bytes.data(), bytes.size(), img, err)) { set_err("tsc_decode_hdr_file: " + err); return TRH_ERR_INVALID_ARG; }
+    *rgba_out = (float*)malloc(img.rgba.size() * sizeof(float));
+    if (!*rgba_out) { set_err("tsc_decode_hdr_file: out of memory"); return TRH_ERR_LIMIT; }
+    memcpy(*rgba_out, img.rgba.data(), img.rgba.size() * sizeof(float));
+    *w_out = img.width;
+    *h_out = img.height;
+    return TRH_OK;
+}
+
+void tsc_free_pixels(void* p) { free(p); }
 
 int tsc_fill_desc(const tsc_scene* cs, trh_scene_desc* out) {
     if (!cs || !out) { set_err("tsc_fill_desc: NULL argument"); return TRH_ERR_INVALID_ARG; }

@@ -20,7 +20,7 @@ class Scene:
     asset_root (the reference runs with its repository root as CWD).
     """
 
-    def __init__(self, scn_path, width=0, height=0, asset_root=None, missing_hdr="synthetic"):
+    def __init__(self, scn_path, width=0, height=0, asset_root=None, missing_hdr="synthetic", decoder="builtin"):
         self._lib = capi.scene_lib()
         self.asset_root = asset_root or capi.ASSET_ROOT
         if not os.path.isabs(scn_path) and not os.path.exists(scn_path):
@@ -30,37 +30,37 @@ class Scene:
         if not self._h:
             raise SceneError(self._lib.tsc_last_error().decode())
         self.synthetic_textures = []
-        self._decode_textures(missing_hdr)
+        self._decode_textures(missing_hdr, decoder)
         self._desc = capi.trh_scene_desc()
         rc = self._lib.tsc_fill_desc(self._h, C.byref(self._desc))
         if rc:
             raise SceneError(self._lib.tsc_last_error().decode())
 
     # -- textures -------------------------------------------------------------------------
-    def _decode_textures(self, missing_hdr):
-        """Image decoding (stb_image in the reference, src/scene.cpp:23-48; PIL here):
-        8-bit images are expanded to RGBA8 like stbi_load(..., 4) (grey -> rgb replicate,
-        alpha 255). A missing .hdr is replaced by the documented synthetic probe."""
+    def _decode_textures(self, missing_hdr, decoder):
+        """Image decoding (stb_image in the reference, src/scene.cpp:23-48). Default: the scene
+        library's own JPEG / Radiance-HDR decoders (tsc_decode_textures), the same path the C++
+        host takes. decoder="pil" decodes 8-bit images with PIL instead (formats the built-in
+        decoders do not cover, e.g. PNG): expanded to RGBA8 like stbi_load(..., 4). A missing
+        .hdr is replaced by the documented synthetic probe."""
         n = self._lib.tsc_texture_count(self._h)
         for i in range(n):
             info = capi.tsc_texture_info()
             self._lib.tsc_get_texture_info(self._h, i, C.byref(info))
             rel = info.path.decode()
             full = rel if os.path.isabs(rel) else os.path.join(self.asset_root, rel)
-            if info.is_hdr:
-                if os.path.exists(full):
-                    raise SceneError(f"{rel}: Radiance .hdr decoding is not implemented yet")
+            if info.is_hdr and not os.path.exists(full):
                 if missing_hdr != "synthetic":
                     raise SceneError(f"{rel} is missing")
-                rc = self._lib.tsc_set_texture_synthetic_sky(self._h, i)
                 self.synthetic_textures.append(rel)
-            else:
+            elif decoder == "pil" and not info.is_hdr:
                 from PIL import Image
                 img = Image.open(full).convert("RGBA")
                 a = np.ascontiguousarray(np.asarray(img, dtype=np.uint8))
-                rc = self._lib.tsc_set_texture_u8(self._h, i, a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p))
-            if rc:
-                raise SceneError(self._lib.tsc_last_error().decode())
+                if self._lib.tsc_set_texture_u8(self._h, i, a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p)):
+                    raise SceneError(self._lib.tsc_last_error().decode())
+        if self._lib.tsc_decode_textures(self._h, 1 if missing_hdr == "synthetic" else 0):
+            raise SceneError(self._lib.tsc_last_error().decode())
 
     # -- accessors ------------------------------------------------------------------------
     @property
