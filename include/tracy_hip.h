@@ -219,6 +219,7 @@ typedef struct trh_bvh_info {
     uint64_t tri_bytes;
     double   sah_cost;
     double   build_ms;
+    double   fp16_inflation;  /* box-area growth of the 32-byte fp16 records; node_bytes / node_count tells which format is in use */
 } trh_bvh_info;
 int trh_get_bvh_info(trh_context* ctx, trh_bvh_info* out);
 

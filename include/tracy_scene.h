@@ -80,6 +80,13 @@ int tsc_decode_jpeg_file(const char* path, uint32_t* w_out, uint32_t* h_out, uin
 int tsc_decode_hdr_file(const char* path, uint32_t* w_out, uint32_t* h_out, float** rgba_out);
 void tsc_free_pixels(void* p);
 
+/* Stress variant of a scene ("4x / 16x midpoint-subdivided dragon"): every
+ * mesh with at least min_triangles triangles has each triangle split into four at its edge
+ * midpoints, `levels` times. Shared edges share the new vertex; attributes are averaged; the surface
+ * (and so the image) is unchanged, only the triangle count grows 4^levels-fold. Not part of the
+ * reference; a fixed rule so that the larger workloads are reproducible. */
+int tsc_subdivide(tsc_scene* s, uint32_t min_triangles, uint32_t levels);
+
 /* Fills a trh_scene_desc whose pointers stay valid until tsc_free / the next tsc_set_*.
  * Fails if a referenced texture has no pixels yet. */
 int tsc_fill_desc(const tsc_scene* s, trh_scene_desc* out);

@@ -265,3 +265,68 @@ def test_full_size_hits_lie_on_their_triangles(dragon_full):
         d /= np.linalg.norm(d)
         pr = eye + float(t[y, x]) * d
         assert np.linalg.norm(pr - pb) <= 2e-3, (pr, pb)
+
+
+# ----------------------------------------------------------------------------- node record formats
+FAR_SCN = """SCN far_apart
+OUT 96 54
+CAM (500,0.02,0.6) (500,0,0) (0,1,0) 20
+SKY (0.6,0.7,0.9)
+MTL grey (0.7,0.7,0.7) 0.9 0.0
+MTL metal (0.9,0.8,0.5) 0.2 1.0
+OBJ S (0,0,0) 0.05 grey
+OBJ S (500,0,0) 0.05 metal
+OBJ S (500.11,0,0) 0.05 grey
+"""
+
+
+def test_fp16_records_fall_back_to_fp32_when_they_would_inflate(tmp_path, monkeypatch):
+    """Small geometry far from the BVH frame centre: half-float bounds (11 significant bits) would
+    blow the boxes up, the builder's inflation measure must select the 64-byte fp32 records, and
+    either format must give the oracle's hits (quantised boxes only ever contain the exact ones)."""
+    from tracy_amd import Scene, HipTrace
+    from oracle.oracle import CpuRef
+    scn = tmp_path / "far.scn"
+    scn.write_text(FAR_SCN)
+    sc = Scene(str(scn))
+    ref_ids, ref_t, _ = CpuRef(sc).primary_hits()
+    assert (ref_ids != MISS).mean() > 0.05
+    images = {}
+    for fmt in (None, "16", "32"):
+        if fmt is None:
+            monkeypatch.delenv("TRH_NODE_FORMAT", raising=False)
+        else:
+            monkeypatch.setenv("TRH_NODE_FORMAT", fmt)
+        mod = HipTrace()
+        mod.Startup(sc)
+        info = mod.bvh_info()
+        rec = info["node_bytes"] // info["node_count"]
+        assert rec == (32 if fmt == "16" else 64)          # default (None) must have fallen back
+        assert info["fp16_inflation"] > 1.25
+        ids, t, _ = mod.primary_hits()
+        assert np.array_equal(ids, ref_ids)
+        assert np.array_equal(t[ids != MISS], ref_t[ids != MISS])
+        mod.render(0, 8)
+        images[fmt] = mod.resolve()[0]
+        mod.Shutdown()
+    # same paths, but the order in which a pixel's samples are summed follows the traversal schedule
+    assert np.array_equal(images[None], images["32"])
+    assert np.allclose(images["16"], images["32"], rtol=2e-6, atol=1e-7)
+
+
+def test_both_record_formats_render_the_same_dragon(scene_loader, monkeypatch):
+    from tracy_amd import HipTrace
+    sc = scene_loader("dragon", 160, 90)
+    out = {}
+    for fmt in ("16", "32"):
+        monkeypatch.setenv("TRH_NODE_FORMAT", fmt)
+        mod = HipTrace()
+        mod.Startup(sc)
+        info = mod.bvh_info()
+        assert info["node_bytes"] == info["node_count"] * (32 if fmt == "16" else 64)
+        assert 1.0 <= info["fp16_inflation"] < 1.25        # dense geometry around the frame centre: fp16 is the default
+        mod.render(0, 16)
+        out[fmt] = (mod.resolve()[0], mod.stats()["rays"])
+        mod.Shutdown()
+    assert out["16"][1] == out["32"][1]                    # identical ray counts: identical paths
+    assert np.allclose(out["16"][0], out["32"][0], rtol=2e-6, atol=1e-7)   # summation order follows the schedule

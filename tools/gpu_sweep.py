@@ -5,14 +5,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     from tracy_amd import Scene, HipTrace
     scene, w, h, spp, pipe = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
-    sc = Scene(f"data/scenes/{scene}.scn", w, h)
+    sc = Scene(f"data/scenes/{scene}.scn", w, h, subdivide=int(os.environ.get("TRH_SUBDIVIDE", "0")))
     mod = HipTrace(pipeline=pipe); mod.Startup(sc)
+    mod.render(0, 4, stats=True); st0 = mod.stats(reset=True); mod.reset(); bi = mod.bvh_info()
     mod.render(0, spp); mod.synchronize(); mod.stats(reset=True)
     best = 1e9
     for i in range(3):
         t0 = time.time(); mod.render(1000 + i * spp, spp); mod.synchronize(); best = min(best, time.time() - t0)
     st = mod.stats(reset=True)
-    print(json.dumps({"ms": best * 1e3, "msamples": w * h * spp / best / 1e6, "mrays": st["rays"] / 3 / best / 1e6}))
+    print(json.dumps({"ms": best * 1e3, "msamples": w * h * spp / best / 1e6, "mrays": st["rays"] / 3 / best / 1e6,
+                      "tris": bi["tri_count"], "nodes": bi["node_count"], "depth": bi["max_depth"], "build_ms": round(bi["build_ms"], 1),
+                      "n_box": round(st0["box_tests"] / st0["rays"], 2), "n_tri": round(st0["tri_tests"] / st0["rays"], 2)}))
     sys.exit(0)
 configs = []
 for a in sys.argv[1:]:

@@ -50,7 +50,8 @@ class trh_stats(C.Structure):
 
 class trh_bvh_info(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("tri_count", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
-                ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("sah_cost", C.c_double), ("build_ms", C.c_double)]
+                ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("sah_cost", C.c_double), ("build_ms", C.c_double),
+                ("fp16_inflation", C.c_double)]
 
 
 class tsc_camera(C.Structure):
@@ -80,6 +81,7 @@ SCENE_SYMBOLS = {
     "tsc_decode_jpeg_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8))]),
     "tsc_decode_hdr_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]),
     "tsc_free_pixels": (None, [C.c_void_p]),
+    "tsc_subdivide": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "tsc_fill_desc": (C.c_int, [C.c_void_p, C.POINTER(trh_scene_desc)]),
 }
 

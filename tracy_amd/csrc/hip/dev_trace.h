@@ -129,7 +129,7 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 d, float t, uint32_t id
 }
 
 // ------------------------------------------------------------------ nearest hit
-// Resumable stack traversal of the BVH2 records (32-byte fp16 form; 64-byte fp32 form with -DTRH_NODE32). The state lives in registers (Trav) plus
+// Resumable stack traversal of the BVH2 records (32-byte fp16 form, or the 64-byte fp32 fallback). The state lives in registers (Trav) plus
 // this lane's LDS stack column (entry i at stack[i * TRH_BLOCK]); a kernel may run trav_inner /
 // trav_leaf for a while, do something else (shade other lanes, refill) and come back.
 struct Trav {
@@ -142,11 +142,7 @@ struct Trav {
 DEVFN bool trav_active(const Trav& tv) { return tv.sp >= 0; }
 
 DEVFN void trav_begin(const DevScene& sc, Trav& tv, V3 o, V3 d) {
-#ifdef TRH_NODE32
-    tv.inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    tv.oi = o * tv.inv;
-#else
-    // The fp16 bounds live in the frame x' = (x - c) * s with s a power of two, so
+    // Node bounds live in the frame x' = (x - c) * s with s a power of two (c = 0, s = 1 for fp32 records), so
     // t = (x - o) / d = x' * (1 / (d s)) - (o - c) * (1 / d): one fma per plane, as before.
     // |1/d| is clamped so that the product with 1/s stays finite (only matters for s < 1, i.e. scenes
     // larger than +-32768 units): a direction change of < 1e-36, far inside the box padding.
@@ -157,7 +153,6 @@ DEVFN void trav_begin(const DevScene& sc, Trav& tv, V3 o, V3 d) {
                       __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -lim, lim));
     tv.oi = mk((o.x - sc.frame_c[0]) * inv.x, (o.y - sc.frame_c[1]) * inv.y, (o.z - sc.frame_c[2]) * inv.z);
     tv.inv = inv * sc.frame_sinv;
-#endif
     tv.hit.t = 3.402823466e+38f;  // HitData.t = FLT_MAX (cpu_trace.cpp:119)
     tv.hit.u = tv.hit.v = 0.f;
     tv.hit.prim = -1;
@@ -175,58 +170,53 @@ DEVFN void trav_pop(Trav& tv, const int* __restrict__ stack) {
     tv.node = tv.sp < 0 ? -1 : top;   // -1: traversal finished
 }
 
-// one inner-node record: one 64-byte fetch, two slab tests. Precondition: tv.node >= 0.
-template <bool STATS>
+// one inner-node record: one fetch, two slab tests. Precondition: tv.node >= 0.
+template <bool STATS, bool N16>
 DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stack, Counters& cnt) {
-#ifdef TRH_NODE32
-    const float4 n0 = sc.nodes[tv.node * 4 + 0];
-    const float4 n1 = sc.nodes[tv.node * 4 + 1];
-    const float4 nz = sc.nodes[tv.node * 4 + 2];
-    const float4 lk = sc.nodes[tv.node * 4 + 3];
-    const int c0 = __float_as_int(lk.x), c1 = __float_as_int(lk.y);
-#else
-    // 32-byte record: two 16-byte loads; the fp16 -> fp32 conversion is free (v_fma_mix_f32 reads either half)
-    const uint4 qa = sc.nodes16[tv.node * 2 + 0];
-    const uint4 qb = sc.nodes16[tv.node * 2 + 1];
-    const H2 hx0 = __builtin_bit_cast(H2, qa.x), hy0 = __builtin_bit_cast(H2, qa.y);
-    const H2 hx1 = __builtin_bit_cast(H2, qa.z), hy1 = __builtin_bit_cast(H2, qa.w);
-    const H2 hz0 = __builtin_bit_cast(H2, qb.x), hz1 = __builtin_bit_cast(H2, qb.y);
-    struct { float x, y, z, w; } n0 = {(float)hx0.x, (float)hx0.y, (float)hy0.x, (float)hy0.y},
-                                 n1 = {(float)hx1.x, (float)hx1.y, (float)hy1.x, (float)hy1.y},
-                                 nz = {(float)hz0.x, (float)hz0.y, (float)hz1.x, (float)hz1.y};
-    const int c0 = (int)qb.z, c1 = (int)qb.w;
-#endif
-    if (STATS) { cnt.box_tests += 2; if (first_active_lane()) cnt.w_inner += 1; }
-#ifdef TRH_EXP_DUP_LOADS   // perturbation experiment: fetch a second (different) record and keep it alive
-    {
-        const int other = tv.node ^ 1;
-        const float4 q0 = sc.nodes[other * 4 + 0], q1 = sc.nodes[other * 4 + 1], q2 = sc.nodes[other * 4 + 2], q3 = sc.nodes[other * 4 + 3];
-        asm volatile("" ::"v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x));
-    }
-#endif
-    // Slab distances in fused form, one v_fma_f32 per plane: fma(bound, inv, -(o*inv)). This rounds
-    // differently from the reference's (bound - o) * inv (collision.h:121-122), which only matters for
-    // WHICH boxes are visited, never for t/u/v: the builder pads every box by 1e-5 of its size plus
-    // 2e-6 of the scene extent, far more than the difference (DESIGN.md "Box test").
+    // Two record formats, chosen per scene at upload; N16 is a template parameter of every kernel that
+    // traverses (a run-time branch here lets the compiler merge the two tails and lose the free conversion):
+    //  * 32-byte record, fp16 bounds in the BVH frame: two 16-byte loads; the fp16 -> fp32 conversion is
+    //    free (v_fma_mix_f32 reads either half of a register as an fp16 operand);
+    //  * 64-byte record, fp32 bounds: four loads. Fallback for scenes whose geometry is so small against
+    //    its distance from the frame centre that half floats would inflate the boxes (bvh_builder.h).
+    // Slab distances in fused form, one fma per plane: fma(bound, inv, -oi). This rounds differently from
+    // the reference's (bound - o) * inv (collision.h:121-122), which only matters for WHICH boxes are
+    // visited, never for t/u/v: the builder pads every box by 1e-5 of its size plus 2e-6 of the scene
+    // extent, far more than the difference.
     const V3 inv = tv.inv, oi = tv.oi;
-    const float ax0 = __builtin_fmaf(n0.x, inv.x, -oi.x), ax1 = __builtin_fmaf(n0.y, inv.x, -oi.x);
-    const float ay0 = __builtin_fmaf(n0.z, inv.y, -oi.y), ay1 = __builtin_fmaf(n0.w, inv.y, -oi.y);
-    const float az0 = __builtin_fmaf(nz.x, inv.z, -oi.z), az1 = __builtin_fmaf(nz.y, inv.z, -oi.z);
-    const float bx0 = __builtin_fmaf(n1.x, inv.x, -oi.x), bx1 = __builtin_fmaf(n1.y, inv.x, -oi.x);
-    const float by0 = __builtin_fmaf(n1.z, inv.y, -oi.y), by1 = __builtin_fmaf(n1.w, inv.y, -oi.y);
-    const float bz0 = __builtin_fmaf(nz.z, inv.z, -oi.z), bz1 = __builtin_fmaf(nz.w, inv.z, -oi.z);
+    float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
+    int c0, c1;
+    if (N16) {
+        const uint4 qa = sc.nodes16[tv.node * 2 + 0];
+        const uint4 qb = sc.nodes16[tv.node * 2 + 1];
+        const H2 hx0 = __builtin_bit_cast(H2, qa.x), hy0 = __builtin_bit_cast(H2, qa.y);
+        const H2 hx1 = __builtin_bit_cast(H2, qa.z), hy1 = __builtin_bit_cast(H2, qa.w);
+        const H2 hz0 = __builtin_bit_cast(H2, qb.x), hz1 = __builtin_bit_cast(H2, qb.y);
+        ax0 = __builtin_fmaf((float)hx0.x, inv.x, -oi.x); ax1 = __builtin_fmaf((float)hx0.y, inv.x, -oi.x);
+        ay0 = __builtin_fmaf((float)hy0.x, inv.y, -oi.y); ay1 = __builtin_fmaf((float)hy0.y, inv.y, -oi.y);
+        az0 = __builtin_fmaf((float)hz0.x, inv.z, -oi.z); az1 = __builtin_fmaf((float)hz0.y, inv.z, -oi.z);
+        bx0 = __builtin_fmaf((float)hx1.x, inv.x, -oi.x); bx1 = __builtin_fmaf((float)hx1.y, inv.x, -oi.x);
+        by0 = __builtin_fmaf((float)hy1.x, inv.y, -oi.y); by1 = __builtin_fmaf((float)hy1.y, inv.y, -oi.y);
+        bz0 = __builtin_fmaf((float)hz1.x, inv.z, -oi.z); bz1 = __builtin_fmaf((float)hz1.y, inv.z, -oi.z);
+        c0 = (int)qb.z; c1 = (int)qb.w;
+    } else {
+        const float4 n0 = sc.nodes[tv.node * 4 + 0];
+        const float4 n1 = sc.nodes[tv.node * 4 + 1];
+        const float4 nz = sc.nodes[tv.node * 4 + 2];
+        const float4 lk = sc.nodes[tv.node * 4 + 3];
+        ax0 = __builtin_fmaf(n0.x, inv.x, -oi.x); ax1 = __builtin_fmaf(n0.y, inv.x, -oi.x);
+        ay0 = __builtin_fmaf(n0.z, inv.y, -oi.y); ay1 = __builtin_fmaf(n0.w, inv.y, -oi.y);
+        az0 = __builtin_fmaf(nz.x, inv.z, -oi.z); az1 = __builtin_fmaf(nz.y, inv.z, -oi.z);
+        bx0 = __builtin_fmaf(n1.x, inv.x, -oi.x); bx1 = __builtin_fmaf(n1.y, inv.x, -oi.x);
+        by0 = __builtin_fmaf(n1.z, inv.y, -oi.y); by1 = __builtin_fmaf(n1.w, inv.y, -oi.y);
+        bz0 = __builtin_fmaf(nz.z, inv.z, -oi.z); bz1 = __builtin_fmaf(nz.w, inv.z, -oi.z);
+        c0 = __float_as_int(lk.x); c1 = __float_as_int(lk.y);
+    }
+    if (STATS) { cnt.box_tests += 2; if (first_active_lane()) cnt.w_inner += 1; }
     const float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.f));
     const float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), tv.hit.t));
     const float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.f));
     const float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), tv.hit.t));
-#ifdef TRH_EXP_DUP_VALU   // perturbation experiment: ~50 extra dependent-free VALU ops per step
-    {
-        float a = ax0, b = bx0;
-#pragma unroll
-        for (int k = 0; k < 25; ++k) { a = a * 1.0001f + ay0; b = b * 0.9999f + by0; }
-        asm volatile("" ::"v"(a), "v"(b));
-    }
-#endif
     const bool h0 = tmin0 <= tmax0;
     const bool h1 = tmin1 <= tmax1;
     const bool swp = h1 && (!h0 || tmin1 < tmin0);   // child 1 is the nearer (or the only) hit
@@ -284,12 +274,12 @@ DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__
 #endif
 }
 
-template <bool STATS>
+template <bool STATS, bool N16>
 DEVFN void intersect(const DevScene& sc, V3 o, V3 d, Hit& hit, int* __restrict__ stack, Counters& cnt) {
     Trav tv;
     trav_begin(sc, tv, o, d);
     while (trav_active(tv)) {
-        while (tv.node >= 0) trav_inner<STATS>(sc, o, tv, stack, cnt);
+        while (tv.node >= 0) trav_inner<STATS, N16>(sc, o, tv, stack, cnt);
         if (trav_active(tv)) trav_leaf<STATS>(sc, o, d, tv, stack, cnt);
     }
     hit = tv.hit;

@@ -29,7 +29,8 @@ struct DevTexture {
 
 // Everything a kernel needs, passed by value as a kernel argument.
 struct DevScene {
-    const float4* nodes;       // 4 float4 per fp32 inner-node record (see bvh_builder.h); only with -DTRH_NODE32
+    // exactly one of the two is non-NULL (chosen at upload from the builder's inflation measure):
+    const float4* nodes;       // 4 float4 per fp32 inner-node record (see bvh_builder.h)
     const uint4* nodes16;      // 2 uint4 per compact record: fp16 bounds in the BVH frame + 2 child links
     const float4* tris;        // 3 float4 per primitive, leaf order: (v0, id) (e1, 0) (e2, 0)
     const float4* shade;       // 4 float4 per primitive: n0 n1 n2 (9) uv0 uv1 uv2 (6) material (1)

@@ -1,7 +1,7 @@
 // tracy_hip.hip -- gfx950 kernels and the C ABI of include/tracy_hip.h.
 //
 // Kernels (all hand-written HIP for CDNA4, wave64):
-//   k_megakernel<STATS>   persistent waves pull 8x8-pixel tiles; every lane owns one pixel and
+//   k_megakernel<STATS, N16>   persistent waves pull 8x8-pixel tiles; every lane owns one pixel and
 //                         regenerates its next sample in place as soon as its path ends, so the
 //                         traversal loop stays full until the tile's samples run out.
 //   k_primary_hits        parity probe (a): nearest hit of un-jittered pixel-centre rays.
@@ -63,7 +63,7 @@ DEVFN void flush_counters(const Counters& c, DevCounters* g) {
 // k_megakernel_simple: first-generation kernel, kept for A/B measurements (TRH_PIPELINE_MEGAKERNEL_SIMPLE).
 // One lane owns one pixel and loops over its samples; a wave waits for its slowest lane every bounce.
 // ---------------------------------------------------------------------------------------
-template <bool STATS>
+template <bool STATS, bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                                                                  DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
     __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, Re
             if (__ballot(alive) == 0ull) break;
             if (alive) {
                 Hit hit;
-                intersect<STATS>(sc, ps.o, ps.d, hit, stack, cnt);
+                intersect<STATS, N16>(sc, ps.o, ps.d, hit, stack, cnt);
                 alive = shade<STATS>(sc, ps, hit, cnt);
                 if (!alive) {
                     acc = acc + ps.radiance;  // samples are summed in increasing sample index
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, Re
 #ifndef TRH_MEGA_WAVES_PER_EU
 #define TRH_MEGA_WAVES_PER_EU 4
 #endif
-template <bool STATS>
+template <bool STATS, bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) __attribute__((amdgpu_waves_per_eu(TRH_MEGA_WAVES_PER_EU, TRH_MEGA_WAVES_PER_EU)))
 void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                                                           DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
@@ -232,7 +232,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                 if (nI != 0u && nI * 4u >= nL * rp.sched_beta4) {
 #pragma unroll
                     for (int r = 0; r < TRH_INNER_REPEAT; ++r)
-                        if (tv.node >= 0) trav_inner<STATS>(sc, ps.o, tv, stack, cnt);
+                        if (tv.node >= 0) trav_inner<STATS, N16>(sc, ps.o, tv, stack, cnt);
                 } else {
                     if (tv.node < -1) trav_leaf<STATS>(sc, ps.o, ps.d, tv, stack, cnt);
                 }
@@ -255,6 +255,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
     flush_counters<STATS>(cnt, counters);
 }
 
+template <bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) void k_primary_hits(DevScene sc, uint32_t* __restrict__ ids, float* __restrict__ t_out, float2* __restrict__ uv_out) {
     __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
     int* stack = &s_stack[threadIdx.x];
@@ -267,12 +268,13 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_primary_hits(DevScene sc, uint32_
     camera_ray(sc, u, v, o, d);
     Hit hit;
     Counters cnt = {};
-    intersect<false>(sc, o, d, hit, stack, cnt);
+    intersect<false, N16>(sc, o, d, hit, stack, cnt);
     ids[p] = hit.id;
     t_out[p] = hit.t;
     uv_out[p] = make_float2(hit.u, hit.v);
 }
 
+template <bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) void k_sample_radiance(DevScene sc, uint32_t sample, uint32_t seed_hash, float4* __restrict__ out) {
     __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
     int* stack = &s_stack[threadIdx.x];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_sample_radiance(DevScene sc, uint
     bool alive = true;
     while (alive) {
         Hit hit;
-        intersect<false>(sc, ps.o, ps.d, hit, stack, cnt);
+        intersect<false, N16>(sc, ps.o, ps.d, hit, stack, cnt);
         alive = shade<false>(sc, ps, hit, cnt);
     }
     out[p] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, (float)ps.bounce);
@@ -381,7 +383,7 @@ struct trh_context {
     double kernel_ms = 0.0;
     uint64_t launches = 0;
     trh_bvh_info bvh{};
-    int simple_grid = 0, simple_grid_stats = 0;
+    int simple_grid[2][2] = {{0, 0}, {0, 0}};
     uint32_t refill_thresh = 24;
     uint32_t sched_beta4 = 6;
     size_t lds_pad = 0;
@@ -434,12 +436,12 @@ int collect_timings(trh_context* c) {
     return TRH_OK;
 }
 
-template <bool STATS>
+template <bool STATS, bool N16>
 int launch_megakernel_simple(trh_context* c, RenderParams rp) {
-    int& grid = STATS ? c->simple_grid_stats : c->simple_grid;
+    int& grid = c->simple_grid[STATS][N16];
     if (grid == 0) {
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel_simple<STATS>, TRH_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel_simple<STATS, N16>, TRH_BLOCK, 0));
         if (per_cu < 1) per_cu = 1;
         grid = per_cu * c->num_cus;
     }
@@ -447,12 +449,12 @@ int launch_megakernel_simple(trh_context* c, RenderParams rp) {
     rp.tiles_x = (uint32_t)(c->sc.width + 7) / 8;
     rp.tiles_y = (uint32_t)(c->sc.height + 7) / 8;
     HIP_TRY(hipMemsetAsync(c->tile_counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL(k_megakernel_simple<STATS>, dim3(grid), dim3(TRH_BLOCK), 0, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
+    hipLaunchKernelGGL((k_megakernel_simple<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), 0, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
     HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
 
-template <bool STATS>
+template <bool STATS, bool N16>
 int launch_megakernel(trh_context* c, RenderParams rp) {
     // tile = 8x8 pixels x spp items; with few samples per call use 16x16 pixels so that a wave still
     // has several items per lane to schedule
@@ -467,11 +469,11 @@ int launch_megakernel(trh_context* c, RenderParams rp) {
     size_t lds = ((size_t)rp.stack_entries * TRH_BLOCK + (size_t)TRH_WAVES_PER_BLOCK * (3u << (wl + hl))) * 4;
     lds += c->lds_pad;   // development knob: lowers occupancy to measure latency sensitivity
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS>, TRH_BLOCK, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS, N16>, TRH_BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     const int grid = per_cu * c->num_cus;
     HIP_TRY(hipMemsetAsync(c->tile_counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL(k_megakernel<STATS>, dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
+    hipLaunchKernelGGL((k_megakernel<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
     HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
@@ -517,6 +519,7 @@ int wf_ensure(trh_context* c, size_t items) {
     return TRH_OK;
 }
 
+template <bool N16>
 int launch_wavefront(trh_context* c, const RenderParams& rp) {
     const uint32_t npix = (uint32_t)(c->sc.width * c->sc.height);
     const uint64_t kItemBudget = 1ull << 28;   // 4 GiB of float4 per batch at most
@@ -527,7 +530,7 @@ int launch_wavefront(trh_context* c, const RenderParams& rp) {
     const uint32_t stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u);
     const size_t lds = (size_t)stack_entries * TRH_BLOCK * 4;
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend, TRH_BLOCK, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<N16>, TRH_BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     const int extend_grid = per_cu * c->num_cus;
     const dim3 pool_grid((pool + 255) / 256);
@@ -547,7 +550,7 @@ int launch_wavefront(trh_context* c, const RenderParams& rp) {
             hipLaunchKernelGGL(k_wf_generate, pool_grid, dim3(256), 0, c->stream, c->sc, c->wf, q_next, rp.spp_begin + done, rp.seed32);
             hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, c->stream, c->wf);
             std::swap(q_cur, q_next);
-            hipLaunchKernelGGL(k_wf_extend, dim3(extend_grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, c->wf, q_cur, stack_entries,
+            hipLaunchKernelGGL(k_wf_extend<N16>, dim3(extend_grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, c->wf, q_cur, stack_entries,
                                c->refill_thresh, c->sched_beta4);
             hipLaunchKernelGGL(k_wf_shade, dim3((pool + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, c->stream, c->sc, c->wf, q_cur, q_next, c->counters);
             HIP_TRY(hipGetLastError());
@@ -580,9 +583,14 @@ int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
     int rc;
-    if (c->pipeline == TRH_PIPELINE_WAVEFRONT && !stats) rc = launch_wavefront(c, rp);
-    else if (c->pipeline == TRH_PIPELINE_MEGAKERNEL_SIMPLE) rc = stats ? launch_megakernel_simple<true>(c, rp) : launch_megakernel_simple<false>(c, rp);
-    else rc = stats ? launch_megakernel<true>(c, rp) : launch_megakernel<false>(c, rp);
+    const bool n16 = c->sc.nodes16 != nullptr;   // node record format of this scene (chosen at upload)
+    if (c->pipeline == TRH_PIPELINE_WAVEFRONT && !stats) rc = n16 ? launch_wavefront<true>(c, rp) : launch_wavefront<false>(c, rp);
+    else if (c->pipeline == TRH_PIPELINE_MEGAKERNEL_SIMPLE)
+        rc = stats ? (n16 ? launch_megakernel_simple<true, true>(c, rp) : launch_megakernel_simple<true, false>(c, rp))
+                   : (n16 ? launch_megakernel_simple<false, true>(c, rp) : launch_megakernel_simple<false, false>(c, rp));
+    else
+        rc = stats ? (n16 ? launch_megakernel<true, true>(c, rp) : launch_megakernel<true, false>(c, rp))
+                   : (n16 ? launch_megakernel<false, true>(c, rp) : launch_megakernel<false, false>(c, rp));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->pending.emplace_back(e0, e1);
@@ -732,14 +740,26 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     DevScene sc{};
     float* dp = nullptr;
     int rc;
-    if ((rc = dev_alloc_copy(c, r.nodes.data(), r.nodes.size(), &dp))) return rc;
-    sc.nodes = (const float4*)dp;
-    uint32_t* dq = nullptr;
-    if ((rc = dev_alloc_copy(c, r.nodes16.data(), r.nodes16.size(), &dq))) return rc;
-    sc.nodes16 = (const uint4*)dq;
-    memcpy(sc.frame_c, r.frame_center, 12);
-    sc.frame_sinv = 1.f / r.frame_scale;
-    sc.frame_inv_lim = r.frame_scale < 1.f ? 3.0e38f * r.frame_scale : 3.402823466e+38f;
+    // node record format: 32-byte fp16 records unless the quantisation would inflate the boxes too much
+    bool use_fp16 = r.fp16_inflation <= bvh::kMaxFp16Inflation;
+    if (const char* e = getenv("TRH_NODE_FORMAT")) {   // development / test knob: 16 or 32
+        if (atoi(e) == 16) use_fp16 = true;
+        if (atoi(e) == 32) use_fp16 = false;
+    }
+    if (use_fp16) {
+        uint32_t* dq = nullptr;
+        if ((rc = dev_alloc_copy(c, r.nodes16.data(), r.nodes16.size(), &dq))) return rc;
+        sc.nodes16 = (const uint4*)dq;
+        memcpy(sc.frame_c, r.frame_center, 12);
+        sc.frame_sinv = 1.f / r.frame_scale;
+        sc.frame_inv_lim = r.frame_scale < 1.f ? 3.0e38f * r.frame_scale : 3.402823466e+38f;
+    } else {
+        if ((rc = dev_alloc_copy(c, r.nodes.data(), r.nodes.size(), &dp))) return rc;
+        sc.nodes = (const float4*)dp;
+        sc.frame_c[0] = sc.frame_c[1] = sc.frame_c[2] = 0.f;
+        sc.frame_sinv = 1.f;
+        sc.frame_inv_lim = 3.402823466e+38f;
+    }
     if ((rc = dev_alloc_copy(c, r.tris.data(), r.tris.size(), &dp))) return rc;
     sc.tris = (const float4*)dp;
     if ((rc = dev_alloc_copy(c, shade.data(), shade.size(), &dp))) return rc;
@@ -813,7 +833,8 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     c->bvh.tri_count = (uint32_t)nprim;
     c->bvh.max_depth = r.max_depth;
     c->bvh.max_leaf_size = r.max_leaf;
-    c->bvh.node_bytes = r.nodes16.size() * 4;   // the 32-byte records the kernels traverse
+    c->bvh.node_bytes = use_fp16 ? r.nodes16.size() * 4 : r.nodes.size() * 4;   // the records the kernels traverse
+    c->bvh.fp16_inflation = r.fp16_inflation;
     c->bvh.tri_bytes = r.tris.size() * 4;
     c->bvh.sah_cost = r.sah_cost;
     c->bvh.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -916,7 +937,7 @@ int trh_primary_hits(trh_context* c, uint32_t* ids_host, float* t_host, float* u
     HIP_TRY(hipMalloc(&d_ids, (size_t)n * 4));
     HIP_TRY(hipMalloc(&d_t, (size_t)n * 4));
     HIP_TRY(hipMalloc(&d_uv, (size_t)n * 8));
-    hipLaunchKernelGGL(k_primary_hits, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, (uint32_t*)d_ids, (float*)d_t, (float2*)d_uv);
+    hipLaunchKernelGGL(c->sc.nodes16 ? k_primary_hits<true> : k_primary_hits<false>, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, (uint32_t*)d_ids, (float*)d_t, (float2*)d_uv);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ids_host, d_ids, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && t_host) e = hipMemcpyAsync(t_host, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
@@ -934,7 +955,7 @@ int trh_sample_radiance(trh_context* c, uint32_t sample_index, uint64_t seed, fl
     const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
     void* d_out = nullptr;
     HIP_TRY(hipMalloc(&d_out, (size_t)n * sizeof(float4)));
-    hipLaunchKernelGGL(k_sample_radiance, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, sample_index, seed_hash_of(seed), (float4*)d_out);
+    hipLaunchKernelGGL(c->sc.nodes16 ? k_sample_radiance<true> : k_sample_radiance<false>, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, sample_index, seed_hash_of(seed), (float4*)d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(rgba_host, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

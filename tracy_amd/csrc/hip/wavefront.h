@@ -89,6 +89,7 @@ __global__ void k_wf_advance(WfBuffers wf) {
     *wf.ctl = c;
 }
 
+template <bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers wf, const uint32_t* __restrict__ q_cur, uint32_t stack_entries,
                                                          uint32_t refill_thresh, uint32_t sched_beta4) {
     extern __shared__ int s_dyn[];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers 
             const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
             if ((nI | nL) == 0u || nP - nI - nL >= refill_thresh) break;
             if (nI != 0u && nI * 4u >= nL * sched_beta4) {
-                if (tv.node >= 0) trav_inner<false>(sc, o, tv, stack, cnt);
+                if (tv.node >= 0) trav_inner<false, N16>(sc, o, tv, stack, cnt);
             } else {
                 if (tv.node < -1) trav_leaf<false>(sc, o, d, tv, stack, cnt);
             }

@@ -262,6 +262,8 @@ struct Builder {
         for (int a = 0; a < 3; ++a) out.frame_center[a] = (float)c[a];
         out.frame_scale = (float)s;
         out.nodes16.assign(n * 8, 0u);
+        double area_exact = 0.0, area_quant = 0.0;
+        auto half_area = [](double dx, double dy, double dz) { return (dx < 0 || dy < 0 || dz < 0) ? 0.0 : dx * dy + dy * dz + dz * dx; };
         for (size_t i = 0; i < n; ++i) {
             const float* r = &out.nodes[i * 16];
             uint32_t* q = &out.nodes16[i * 8];
@@ -276,7 +278,18 @@ struct Builder {
             q[4] = pack(r[8], r[9], 2);  q[5] = pack(r[10], r[11], 2);
             memcpy(&q[6], &r[12], 4);
             memcpy(&q[7], &r[13], 4);
+            // inflation measure (boxes of empty / padding leaves are skipped: |bound| >= 1e30)
+            const int ex[2][6] = {{0, 1, 2, 3, 8, 9}, {4, 5, 6, 7, 10, 11}};   // minx maxx miny maxy minz maxz in r[]
+            const int qx[2][3] = {{0, 1, 4}, {2, 3, 5}};                        // words holding x, y, z (min | max << 16)
+            for (int c = 0; c < 2; ++c) {
+                if (std::fabs(r[ex[c][0]]) >= 1e30f) continue;
+                area_exact += half_area((double)r[ex[c][1]] - r[ex[c][0]], (double)r[ex[c][3]] - r[ex[c][2]], (double)r[ex[c][5]] - r[ex[c][4]]);
+                double d[3];
+                for (int a = 0; a < 3; ++a) d[a] = ((double)half_to_float((uint16_t)(q[qx[c][a]] >> 16)) - (double)half_to_float((uint16_t)(q[qx[c][a]] & 0xffffu))) / s;
+                area_quant += half_area(d[0], d[1], d[2]);
+            }
         }
+        out.fp16_inflation = area_exact > 0.0 ? area_quant / area_exact : 1.0;
     }
 
     void run() {

@@ -16,6 +16,7 @@ namespace bvh {
 constexpr int kMaxDepth = 32;     // == traversal stack entries per lane (LDS)
 constexpr int kMaxLeafSize = 8;   // leaf count is packed in 4 bits
 constexpr int kSahBins = 16;
+constexpr double kMaxFp16Inflation = 1.25;
 
 struct InputTriangle {
     float v0[3], v1[3], v2[3];
@@ -44,6 +45,11 @@ struct Result {
     std::vector<uint32_t> nodes16;     // 8 words per inner node, same order
     float frame_center[3] = {0.f, 0.f, 0.f};
     float frame_scale = 1.f;           // power of two
+    // sum of the child-box half areas of all records, quantised / exact (>= 1): how much more often a
+    // random ray enters a box because of the fp16 rounding. Near 1 when the geometry is dense around the
+    // frame centre; large when small triangles sit far from it (a half float has 11 significant bits).
+    // The module falls back to the fp32 records above kMaxFp16Inflation.
+    double fp16_inflation = 1.0;
     std::vector<float> tris;           // 12 floats per primitive in leaf order: v0.xyz id | e1.xyz 0 | e2.xyz 0
     std::vector<uint32_t> prim_index;  // leaf-order position -> index into the input triangle array
     uint32_t max_depth = 0;

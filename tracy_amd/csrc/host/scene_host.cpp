@@ -635,6 +635,46 @@ int tsc_set_texture_synthetic_sky(tsc_scene* s, uint32_t i) {
     return rc;
 }
 
+int tsc_subdivide(tsc_scene* s, uint32_t min_triangles, uint32_t levels) {
+    if (!s) { set_err("tsc_subdivide: NULL scene"); return TRH_ERR_INVALID_ARG; }
+    for (uint32_t l = 0; l < levels; ++l) {
+        for (Mesh& m : s->objects) {
+            const size_t ntri = m.idx.size() / 3;
+            if (ntri < min_triangles) continue;
+            if (ntri * 4 > (1u << 24)) { set_err("tsc_subdivide: more than 2^24 triangles in one mesh (24-bit triangle id)"); return TRH_ERR_LIMIT; }
+            std::unordered_map<uint64_t, uint32_t> mid;
+            mid.reserve(ntri * 2);
+            auto midpoint = [&](uint32_t a, uint32_t b) -> uint32_t {
+                const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+                auto it = mid.find(key);
+                if (it != mid.end()) return it->second;
+                const Vertex& va = m.v[a];
+                const Vertex& vb = m.v[b];
+                Vertex n;
+                n.pos = (va.pos + vb.pos) * .5f;
+                n.normal = (va.normal + vb.normal) * .5f;
+                n.uv0 = vec2{(va.uv0.x + vb.uv0.x) * .5f, (va.uv0.y + vb.uv0.y) * .5f};
+                n.tangent = (va.tangent + vb.tangent) * .5f;
+                n.bitangent = (va.bitangent + vb.bitangent) * .5f;
+                const uint32_t id = (uint32_t)m.v.size();
+                m.v.push_back(n);
+                mid.emplace(key, id);
+                return id;
+            };
+            std::vector<uint32_t> out;
+            out.reserve(m.idx.size() * 4);
+            for (size_t t = 0; t < ntri; ++t) {
+                const uint32_t a = m.idx[t * 3], b = m.idx[t * 3 + 1], c = m.idx[t * 3 + 2];
+                const uint32_t ab = midpoint(a, b), bc = midpoint(b, c), ca = midpoint(c, a);
+                const uint32_t tri[12] = {a, ab, ca, ab, b, bc, ca, bc, c, ab, bc, ca};
+                out.insert(out.end(), tri, tri + 12);
+            }
+            m.idx.swap(out);
+        }
+    }
+    return TRH_OK;
+}
+
 int tsc_decode_textures(tsc_scene* s, int synthetic_missing_hdr) {
     if (!s) { set_err("tsc_decode_textures: NULL scene"); return TRH_ERR_INVALID_ARG; }
     for (uint32_t i = 0; i < s->textures.size(); ++i) {

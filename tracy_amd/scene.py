@@ -20,7 +20,8 @@ class Scene:
     asset_root (the reference runs with its repository root as CWD).
     """
 
-    def __init__(self, scn_path, width=0, height=0, asset_root=None, missing_hdr="synthetic", decoder="builtin"):
+    def __init__(self, scn_path, width=0, height=0, asset_root=None, missing_hdr="synthetic", decoder="builtin", subdivide=0,
+                 subdivide_min_triangles=1000):
         self._lib = capi.scene_lib()
         self.asset_root = asset_root or capi.ASSET_ROOT
         if not os.path.isabs(scn_path) and not os.path.exists(scn_path):
@@ -31,6 +32,9 @@ class Scene:
             raise SceneError(self._lib.tsc_last_error().decode())
         self.synthetic_textures = []
         self._decode_textures(missing_hdr, decoder)
+        if subdivide:   # stress variant: 4^subdivide times the triangles of every large mesh, same surface
+            if self._lib.tsc_subdivide(self._h, int(subdivide_min_triangles), int(subdivide)):
+                raise SceneError(self._lib.tsc_last_error().decode())
         self._desc = capi.trh_scene_desc()
         rc = self._lib.tsc_fill_desc(self._h, C.byref(self._desc))
         if rc:
