@@ -36,10 +36,12 @@ def algorithmic_flops(st):
             + 25.0 * miss + 8.0 * st["hits"] + 58.0 * st["samples"])
 
 
-def algorithmic_bytes(st):
-    """Secondary figure: 64 B per inner-node record visit (2 boxes), 48 B per triangle test,
-    172 B per hit (64 B shading record + hit bookkeeping), 16 B per texel, 32 B per sample."""
-    return (32.0 * st["box_tests"] + 48.0 * st["tri_tests"] + 172.0 * st["hits"] + 16.0 * st["tex_fetches"] + 32.0 * st["samples"])
+def algorithmic_bytes(st, node_record_bytes):
+    """Secondary figure: one inner-node record per 2 box tests (32 B fp16 records, 64 B in the fp32
+    fallback), 48 B per triangle test, 172 B per hit (64 B shading record + hit bookkeeping), 16 B
+    per texel, 32 B per sample."""
+    return (0.5 * node_record_bytes * st["box_tests"] + 48.0 * st["tri_tests"] + 172.0 * st["hits"] + 16.0 * st["tex_fetches"]
+            + 32.0 * st["samples"])
 
 
 def cpu_baseline(scene_name, width, height, budget_s=12.0):
@@ -76,6 +78,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save", default=None, help="rank 0: write the resolved image as .npy")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the product path). gloo = rehearsal of the N>1 control flow on a box with fewer GPUs "
+                         "than ranks: ranks share devices and the exchange step is staged through host memory")
     args = ap.parse_args()
 
     import torch
@@ -88,10 +93,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     scene = Scene(f"data/scenes/{args.scene}.scn", args.width, args.height)
     mod = HipTrace(device=local_rank, pipeline=args.pipeline)
@@ -112,6 +122,7 @@ def main():
     mod.render(*sharding.step_sample_range(rank, world, 0, S), stats=True)
     st_algo = mod.stats(reset=True)
     accum.zero_()
+    torch.cuda.synchronize()   # zero_() runs on torch's stream, the module renders on its own
 
     # ---- warmup
     step = 0
@@ -122,6 +133,7 @@ def main():
     if world > 1:
         sharding.reduce_accum_to_root(accum.clone(), dist)   # RCCL warm-up on a scratch copy
     accum.zero_()
+    torch.cuda.synchronize()
     mod.stats(reset=True)
     first_timed = step
 
@@ -141,7 +153,8 @@ def main():
     dt = time.perf_counter() - t0
 
     st = mod.stats(reset=False)
-    t_all = torch.tensor([dt, float(st["rays"]), float(st["samples"])], dtype=torch.float64, device=f"cuda:{local_rank}")
+    t_all = torch.tensor([dt, float(st["rays"]), float(st["samples"])], dtype=torch.float64,
+                         device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = t_all.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -161,7 +174,8 @@ def main():
             np.save(args.save, img)
         kernel_ms = st["kernel_ms"] / max(1, st["launches"])
         flops_launch = algorithmic_flops(st_algo)
-        bytes_launch = algorithmic_bytes(st_algo)
+        bvh = mod.bvh_info()
+        bytes_launch = algorithmic_bytes(st_algo, bvh["node_bytes"] / max(1, bvh["node_count"]))
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -182,16 +196,16 @@ def main():
             "config": {"workload": f"{args.scene}.scn {W}x{H}, {S} spp per step per GPU, {scene.tri_count} triangles, "
                                    f"max 5 bounces + Russian roulette, seed 0xABCDEF (BASELINE.json configs[3])",
                        "spp_per_step": S, "total_spp": S * args.steps * world, "first_sample_index": first_timed * world * S,
-                       "parallelism": f"sample-index sharding x{world}, one sum-reduce to rank 0",
+                       "parallelism": f"sample-index sharding x{world}, one sum-reduce to rank 0" + ("" if args.backend == "nccl" else " (gloo REHEARSAL, not a measurement)"),
                        "pipeline": "megakernel" if not args.pipeline else "wavefront",
-                       "bvh": mod.bvh_info(), "rays_per_sample": total_rays / total_samples},
+                       "bvh": bvh, "rays_per_sample": total_rays / total_samples},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "kernel": "k_megakernel<false>" if not args.pipeline else "wavefront", "kernel_ms_avg": kernel_ms,
                          "flops_per_launch": flops_launch,
                          "per_ray": {"box_tests": st_algo["box_tests"] / st_algo["rays"], "tri_tests": st_algo["tri_tests"] / st_algo["rays"],
                                      "hit_frac": st_algo["hits"] / st_algo["rays"], "tex_fetches": st_algo["tex_fetches"] / st_algo["rays"]},
-                         # secondary: the algorithmic bytes are served by L1/L2/Infinity Cache (hot data = 10 MB);
+                         # secondary: the algorithmic bytes are served by L1/L2/Infinity Cache (hot data = 7.5 MB);
                          # `traffic` above is what actually reaches the fabric. Not an HBM-bound path.
                          "bytes_secondary": {"algorithmic_bytes_per_launch": bytes_launch,
                                              "algorithmic_GBs_all_cache_levels": bytes_launch / (kernel_ms * 1e-3) / 1e9,

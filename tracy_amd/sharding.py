@@ -33,6 +33,12 @@ def reduce_accum_to_root(accum, dist=None):
     """The one exchange step: in-place sum-reduce of the accumulation buffer to rank 0."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return accum
+    if accum.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal / CPU-test backend: stage through host memory (RCCL reduces device memory in place)
+        host = accum.cpu()
+        dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+        accum.copy_(host)
+        return accum
     dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
     return accum
 
