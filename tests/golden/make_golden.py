@@ -21,7 +21,7 @@ from tracy_amd.scene import Scene  # noqa: E402
 from oracle.oracle import CpuRef  # noqa: E402
 
 W, H, SPP = 64, 36, 16
-SCENES = ["cornell", "dragon", "spheres", "random", "testtree", "furnace", "helmet"]
+SCENES = ["cornell", "dragon", "spheres", "random", "testtree", "furnace", "helmet", "bunny", "trimesh"]
 
 if __name__ == "__main__":
     for name in SCENES:

@@ -19,7 +19,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 MISS = 0xFFFFFFFF
-ALL = ["cornell", "dragon", "spheres", "random", "testtree", "furnace", "helmet"]
+ALL = ["cornell", "dragon", "spheres", "random", "testtree", "furnace", "helmet", "bunny", "trimesh"]
 
 
 def srgb(x):

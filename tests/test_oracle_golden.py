@@ -7,7 +7,7 @@ import pytest
 
 from conftest import GOLDEN
 
-SCENES = ["cornell", "dragon", "spheres", "random", "testtree", "furnace", "helmet"]
+SCENES = ["cornell", "dragon", "spheres", "random", "testtree", "furnace", "helmet", "bunny", "trimesh"]
 
 
 @pytest.mark.parametrize("name", SCENES)

@@ -11,6 +11,8 @@ import pytest
     ("random", 13973, 15, 10),      # 7 x 1984 + 7 x 12 + 1
     ("testtree", 4, 4, 5),
     ("furnace", 1984, 1, 2),
+    ("bunny", 69666 + 24, 3, 4),    # stanford_bunny.obj (69 666 faces) + 2 boxes
+    ("trimesh", 3 * 1984 + 12 + 6320, 5, 6),   # 3 spheres + 1 box + teapot.obj (quads fan-triangulated)
 ])
 def test_scene_counts(scene_loader, name, tris, objects, materials):
     sc = scene_loader(name, 64, 36)
