@@ -135,6 +135,7 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 d, float t, uint32_t id
 struct Trav {
     V3 inv;      // rcp(direction) (src/ray.h:18) expressed in the BVH frame: 1 / (d * frame_s)
     V3 oi;       // (origin - frame_c) * rcp(direction): slab distance = fma(bound', inv, -oi)
+    uint32_t selx, sely, selz;   // v_perm_b32 selectors: swap the (min | max << 16) halves of an axis word when d < 0
     int node;    // >= 0: inner-node record; < -1: leaf link ~((first << 4) | count); -1: nothing to traverse
     int sp;      // stack entries in use; < 0 <=> traversal finished
     Hit hit;
@@ -153,6 +154,11 @@ DEVFN void trav_begin(const DevScene& sc, Trav& tv, V3 o, V3 d) {
                       __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -lim, lim));
     tv.oi = mk((o.x - sc.frame_c[0]) * inv.x, (o.y - sc.frame_c[1]) * inv.y, (o.z - sc.frame_c[2]) * inv.z);
     tv.inv = inv * sc.frame_sinv;
+    // fp16 records keep (min | max << 16) per axis: with the halves ordered by the sign of d the low half is
+    // the plane the ray enters through and the high half the one it leaves through -- no min/max per axis
+    tv.selx = (__float_as_uint(d.x) >> 31) ? 0x01000302u : 0x03020100u;
+    tv.sely = (__float_as_uint(d.y) >> 31) ? 0x01000302u : 0x03020100u;
+    tv.selz = (__float_as_uint(d.z) >> 31) ? 0x01000302u : 0x03020100u;
     tv.hit.t = 3.402823466e+38f;  // HitData.t = FLT_MAX (cpu_trace.cpp:119)
     tv.hit.u = tv.hit.v = 0.f;
     tv.hit.prim = -1;
@@ -184,39 +190,45 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
     // visited, never for t/u/v: the builder pads every box by 1e-5 of its size plus 2e-6 of the scene
     // extent, far more than the difference.
     const V3 inv = tv.inv, oi = tv.oi;
-    float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
+    float tmin0, tmax0, tmin1, tmax1;
     int c0, c1;
     if (N16) {
         const uint4 qa = sc.nodes16[tv.node * 2 + 0];
         const uint4 qb = sc.nodes16[tv.node * 2 + 1];
-        const H2 hx0 = __builtin_bit_cast(H2, qa.x), hy0 = __builtin_bit_cast(H2, qa.y);
-        const H2 hx1 = __builtin_bit_cast(H2, qa.z), hy1 = __builtin_bit_cast(H2, qa.w);
-        const H2 hz0 = __builtin_bit_cast(H2, qb.x), hz1 = __builtin_bit_cast(H2, qb.y);
-        ax0 = __builtin_fmaf((float)hx0.x, inv.x, -oi.x); ax1 = __builtin_fmaf((float)hx0.y, inv.x, -oi.x);
-        ay0 = __builtin_fmaf((float)hy0.x, inv.y, -oi.y); ay1 = __builtin_fmaf((float)hy0.y, inv.y, -oi.y);
-        az0 = __builtin_fmaf((float)hz0.x, inv.z, -oi.z); az1 = __builtin_fmaf((float)hz0.y, inv.z, -oi.z);
-        bx0 = __builtin_fmaf((float)hx1.x, inv.x, -oi.x); bx1 = __builtin_fmaf((float)hx1.y, inv.x, -oi.x);
-        by0 = __builtin_fmaf((float)hy1.x, inv.y, -oi.y); by1 = __builtin_fmaf((float)hy1.y, inv.y, -oi.y);
-        bz0 = __builtin_fmaf((float)hz1.x, inv.z, -oi.z); bz1 = __builtin_fmaf((float)hz1.y, inv.z, -oi.z);
+        // order the halves of every axis word by the ray's direction sign: low = entry plane, high = exit plane
+        const H2 hx0 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qa.x, qa.x, tv.selx)), hy0 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qa.y, qa.y, tv.sely));
+        const H2 hx1 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qa.z, qa.z, tv.selx)), hy1 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qa.w, qa.w, tv.sely));
+        const H2 hz0 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qb.x, qb.x, tv.selz)), hz1 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qb.y, qb.y, tv.selz));
+        const float anx = __builtin_fmaf((float)hx0.x, inv.x, -oi.x), afx = __builtin_fmaf((float)hx0.y, inv.x, -oi.x);
+        const float any = __builtin_fmaf((float)hy0.x, inv.y, -oi.y), afy = __builtin_fmaf((float)hy0.y, inv.y, -oi.y);
+        const float anz = __builtin_fmaf((float)hz0.x, inv.z, -oi.z), afz = __builtin_fmaf((float)hz0.y, inv.z, -oi.z);
+        const float bnx = __builtin_fmaf((float)hx1.x, inv.x, -oi.x), bfx = __builtin_fmaf((float)hx1.y, inv.x, -oi.x);
+        const float bny = __builtin_fmaf((float)hy1.x, inv.y, -oi.y), bfy = __builtin_fmaf((float)hy1.y, inv.y, -oi.y);
+        const float bnz = __builtin_fmaf((float)hz1.x, inv.z, -oi.z), bfz = __builtin_fmaf((float)hz1.y, inv.z, -oi.z);
+        // fmaxf / fminf drop a NaN operand (0 * inf on an axis-parallel ray): that axis is ignored, conservatively
+        tmin0 = fmaxf(fmaxf(anx, any), fmaxf(anz, 0.f));
+        tmax0 = fminf(fminf(afx, afy), fminf(afz, tv.hit.t));
+        tmin1 = fmaxf(fmaxf(bnx, bny), fmaxf(bnz, 0.f));
+        tmax1 = fminf(fminf(bfx, bfy), fminf(bfz, tv.hit.t));
         c0 = (int)qb.z; c1 = (int)qb.w;
     } else {
         const float4 n0 = sc.nodes[tv.node * 4 + 0];
         const float4 n1 = sc.nodes[tv.node * 4 + 1];
         const float4 nz = sc.nodes[tv.node * 4 + 2];
         const float4 lk = sc.nodes[tv.node * 4 + 3];
-        ax0 = __builtin_fmaf(n0.x, inv.x, -oi.x); ax1 = __builtin_fmaf(n0.y, inv.x, -oi.x);
-        ay0 = __builtin_fmaf(n0.z, inv.y, -oi.y); ay1 = __builtin_fmaf(n0.w, inv.y, -oi.y);
-        az0 = __builtin_fmaf(nz.x, inv.z, -oi.z); az1 = __builtin_fmaf(nz.y, inv.z, -oi.z);
-        bx0 = __builtin_fmaf(n1.x, inv.x, -oi.x); bx1 = __builtin_fmaf(n1.y, inv.x, -oi.x);
-        by0 = __builtin_fmaf(n1.z, inv.y, -oi.y); by1 = __builtin_fmaf(n1.w, inv.y, -oi.y);
-        bz0 = __builtin_fmaf(nz.z, inv.z, -oi.z); bz1 = __builtin_fmaf(nz.w, inv.z, -oi.z);
+        const float ax0 = __builtin_fmaf(n0.x, inv.x, -oi.x), ax1 = __builtin_fmaf(n0.y, inv.x, -oi.x);
+        const float ay0 = __builtin_fmaf(n0.z, inv.y, -oi.y), ay1 = __builtin_fmaf(n0.w, inv.y, -oi.y);
+        const float az0 = __builtin_fmaf(nz.x, inv.z, -oi.z), az1 = __builtin_fmaf(nz.y, inv.z, -oi.z);
+        const float bx0 = __builtin_fmaf(n1.x, inv.x, -oi.x), bx1 = __builtin_fmaf(n1.y, inv.x, -oi.x);
+        const float by0 = __builtin_fmaf(n1.z, inv.y, -oi.y), by1 = __builtin_fmaf(n1.w, inv.y, -oi.y);
+        const float bz0 = __builtin_fmaf(nz.z, inv.z, -oi.z), bz1 = __builtin_fmaf(nz.w, inv.z, -oi.z);
+        tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.f));
+        tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), tv.hit.t));
+        tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.f));
+        tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), tv.hit.t));
         c0 = __float_as_int(lk.x); c1 = __float_as_int(lk.y);
     }
     if (STATS) { cnt.box_tests += 2; if (first_active_lane()) cnt.w_inner += 1; }
-    const float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.f));
-    const float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), tv.hit.t));
-    const float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.f));
-    const float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), tv.hit.t));
     const bool h0 = tmin0 <= tmax0;
     const bool h1 = tmin1 <= tmax1;
     const bool swp = h1 && (!h0 || tmin1 < tmin0);   // child 1 is the nearer (or the only) hit

@@ -168,6 +168,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
         ps.bounce = 0;
         Trav tv;
         tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
+        tv.selx = tv.sely = tv.selz = 0x03020100u;
         tv.node = -1;
         tv.sp = -1;
         tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers 
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
     Trav tv;
     tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
+    tv.selx = tv.sely = tv.selz = 0x03020100u;
     tv.node = -1;
     tv.sp = -1;
     tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
