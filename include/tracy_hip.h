@@ -223,6 +223,15 @@ typedef struct trh_bvh_info {
 } trh_bvh_info;
 int trh_get_bvh_info(trh_context* ctx, trh_bvh_info* out);
 
+/* Host-only: builds the acceleration structure of a scene description exactly as trh_scene_upload
+ * does (same validation, same builder, no device needed), runs the builder's structural self-check
+ * (every triangle in exactly one leaf, leaf boxes contain their triangles, every fp16 box contains
+ * its fp32 box, limits respected) and returns the number of violations (0 = sound; trh_last_error()
+ * names the first) plus an FNV-1a hash of the record arrays: the layout must not depend on the
+ * number of builder threads (TRH_BUILD_THREADS). No counterpart in the reference (its kd-tree build,
+ * kdtree.h:160-354, is not what the kernels traverse). */
+int trh_bvh_build_host(const trh_scene_desc* scene, trh_bvh_info* info_out, uint64_t* hash_out, uint64_t* violations_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,112 @@
+"""Host BVH builder (csrc/host/bvh_builder.cpp) through the host-only entry trh_bvh_build_host:
+structural self-check on every scene, thread-count independence of the layout, the fp16 inflation
+measure, and the degenerate inputs (empty scene, one triangle, coincident triangles)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tracy_amd import capi
+
+ALL = ["cornell", "dragon", "spheres", "random", "testtree", "furnace", "helmet", "bunny", "trimesh"]
+
+
+def build_host(desc):
+    lib = capi.hip_lib()
+    info, h, bad = capi.trh_bvh_info(), C.c_uint64(), C.c_uint64()
+    rc = lib.trh_bvh_build_host(C.byref(desc), C.byref(info), C.byref(h), C.byref(bad))
+    assert rc == 0, lib.trh_last_error()
+    return info, h.value, bad.value, lib.trh_last_error().decode()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_tree_is_sound(scene_loader, name):
+    sc = scene_loader(name, 64, 36)
+    info, _, bad, why = build_host(sc.desc)
+    assert bad == 0, why
+    assert info.tri_count == sc.tri_count
+    assert 1 <= info.max_depth <= 32 and 1 <= info.max_leaf_size <= 8
+    assert info.node_count >= 1 and info.fp16_inflation >= 1.0
+    # shipped scenes keep their geometry around the centre of mass: fp16 records are in use
+    assert info.node_bytes == 32 * info.node_count and info.fp16_inflation < 1.25
+
+
+def test_layout_does_not_depend_on_builder_threads(scene_loader, monkeypatch):
+    sc = scene_loader("dragon", 64, 36)
+    hashes = {}
+    for t in ("1", "2", "8"):
+        monkeypatch.setenv("TRH_BUILD_THREADS", t)
+        info, h, bad, why = build_host(sc.desc)
+        assert bad == 0, why
+        hashes[t] = (h, info.node_count, info.max_depth, round(info.sah_cost, 9))
+    assert hashes["1"] == hashes["2"] == hashes["8"]
+
+
+def test_subdivided_dragon_and_big_node_parallel_binning(monkeypatch):
+    from tracy_amd import Scene
+    sc = Scene("data/scenes/dragon.scn", 64, 36, subdivide=1)      # 400 024 triangles: the root is binned by several threads
+    assert sc.tri_count == 400024
+    out = {}
+    for t in ("1", "8"):
+        monkeypatch.setenv("TRH_BUILD_THREADS", t)
+        info, h, bad, why = build_host(sc.desc)
+        assert bad == 0, why
+        out[t] = (h, info.node_count)
+    assert out["1"] == out["8"]
+
+
+def make_desc(vertices, indices):
+    v = np.zeros((len(vertices), capi.TRH_VERTEX_FLOATS), dtype=np.float32)
+    v[:, :3] = vertices
+    v[:, 3:6] = (0, 0, 1)
+    idx = np.asarray(indices, dtype=np.uint32)
+    mesh = capi.trh_mesh(0, len(v), 0, len(idx), 1)
+    mats = (capi.trh_material * 2)()
+    for m in mats:
+        for k in range(5):
+            m.tex[k] = capi.TRH_NO_TEXTURE
+    d = capi.trh_scene_desc()
+    d.vertices = v.ctypes.data_as(C.POINTER(C.c_float)); d.vertex_count = len(v)
+    d.indices = idx.ctypes.data_as(C.POINTER(C.c_uint32)); d.index_count = len(idx)
+    d.meshes = C.pointer(mesh); d.mesh_count = 1
+    d.materials = mats; d.material_count = 2
+    d.width, d.height, d.max_bounces, d.flags = 8, 8, 5, 1
+    return d, (v, idx, mesh, mats)
+
+
+def test_degenerate_inputs():
+    d, keep = make_desc([(0, 0, 0)], [])                              # no triangle at all
+    d.mesh_count = 0
+    info, _, bad, why = build_host(d)
+    assert bad == 0 and info.tri_count == 0 and info.node_count == 1, why
+    d, keep = make_desc([(0, 0, 0), (1, 0, 0), (0, 1, 0)], [0, 1, 2])  # one triangle: root record wraps one leaf
+    info, _, bad, why = build_host(d)
+    assert bad == 0 and info.tri_count == 1 and info.node_count == 1 and info.max_depth == 1, why
+    tri = [(0, 0, 0), (1, 0, 0), (0, 1, 0)]
+    d, keep = make_desc(tri, [0, 1, 2] * 100)                         # 100 coincident triangles: SAH cannot split, median must
+    info, _, bad, why = build_host(d)
+    assert bad == 0 and info.tri_count == 100 and info.max_leaf_size <= 8 and info.max_depth <= 32, why
+
+
+def test_far_apart_detail_is_flagged_for_fp32_records():
+    rng = np.random.default_rng(1)
+    verts, idx = [], []
+    for cx in (0.0, 500.0):
+        for k in range(400):
+            p = rng.normal(0, 0.05, 3) + (cx, 0, 0)
+            base = len(verts)
+            verts += [p, p + (0.004, 0, 0), p + (0, 0.004, 0)]
+            idx += [base, base + 1, base + 2]
+    d, keep = make_desc(np.array(verts), idx)
+    info, _, bad, why = build_host(d)
+    assert bad == 0, why
+    assert info.fp16_inflation > 1.25 and info.node_bytes == 64 * info.node_count
+
+
+def test_invalid_descriptions_are_rejected():
+    lib = capi.hip_lib()
+    bad = C.c_uint64()
+    assert lib.trh_bvh_build_host(None, None, None, C.byref(bad)) != 0
+    d, keep = make_desc([(0, 0, 0), (1, 0, 0), (0, 1, 0)], [0, 1, 7])   # vertex index out of range
+    assert lib.trh_bvh_build_host(C.byref(d), None, None, C.byref(bad)) != 0
+    assert b"out of range" in lib.trh_last_error()

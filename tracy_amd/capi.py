@@ -107,6 +107,7 @@ HIP_SYMBOLS = {
     "trh_sample_radiance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]),
     "trh_get_stats": (C.c_int, [C.c_void_p, C.POINTER(trh_stats), C.c_int]),
     "trh_get_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32]),
+    "trh_bvh_build_host": (C.c_int, [C.POINTER(trh_scene_desc), C.POINTER(trh_bvh_info), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "trh_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(trh_bvh_info)]),
 }
 

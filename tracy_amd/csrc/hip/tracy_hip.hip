@@ -569,6 +569,43 @@ int launch_wavefront(trh_context* c, const RenderParams& rp) {
     return TRH_OK;
 }
 
+// validate a scene description and flatten its triangles (world space; the reference bakes transforms at load)
+int flatten_triangles(const trh_scene_desc* d, std::vector<bvh::InputTriangle>& tris, bool& any_normal_map) {
+    if (d->mesh_count > 256) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 256 meshes (8-bit mesh id)");
+    if (d->material_count == 0) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: material 0 (sky) is required");
+    tris.reserve(d->index_count / 3);
+    any_normal_map = false;
+    for (uint32_t m = 0; m < d->material_count; ++m) {
+        for (int k = 0; k < TRH_TEX_COUNT; ++k) {
+            const uint32_t t = d->materials[m].tex[k];
+            if (t != TRH_NO_TEXTURE && t >= d->texture_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: material references a missing texture");
+        }
+        if (d->materials[m].tex[TRH_TEX_NORMAL] != TRH_NO_TEXTURE) any_normal_map = true;
+    }
+    for (uint32_t m = 0; m < d->mesh_count; ++m) {
+        const trh_mesh& me = d->meshes[m];
+        if ((uint64_t)me.first_vertex + me.vertex_count > d->vertex_count || (uint64_t)me.first_index + me.index_count > d->index_count)
+            return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: mesh range out of bounds");
+        if (me.material >= d->material_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: mesh material out of range");
+        if (me.index_count / 3 > 0xffffffu) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 2^24 triangles in one mesh");
+        for (uint32_t t = 0; t < me.index_count / 3; ++t) {
+            bvh::InputTriangle it;
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t li = d->indices[me.first_index + t * 3 + k];
+                if (li >= me.vertex_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: vertex index out of range");
+                const float* v = d->vertices + (size_t)(me.first_vertex + li) * TRH_VERTEX_FLOATS;
+                float* dst = k == 0 ? it.v0 : (k == 1 ? it.v1 : it.v2);
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+            }
+            it.packed_id = (m << 24) | t;
+            tris.push_back(it);
+        }
+    }
+    if (tris.size() >= (1u << 27)) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 2^27 triangles");
+
+    return TRH_OK;
+}
+
 int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed, bool stats) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_render: ctx is NULL");
     if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_render: scene and camera must be uploaded first");
@@ -678,37 +715,9 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_scene(c);
 
-    // ---- validate + flatten triangles (world space; the reference bakes transforms at load)
     std::vector<bvh::InputTriangle> tris;
-    tris.reserve(d->index_count / 3);
     bool any_normal_map = false;
-    for (uint32_t m = 0; m < d->material_count; ++m) {
-        for (int k = 0; k < TRH_TEX_COUNT; ++k) {
-            const uint32_t t = d->materials[m].tex[k];
-            if (t != TRH_NO_TEXTURE && t >= d->texture_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: material references a missing texture");
-        }
-        if (d->materials[m].tex[TRH_TEX_NORMAL] != TRH_NO_TEXTURE) any_normal_map = true;
-    }
-    for (uint32_t m = 0; m < d->mesh_count; ++m) {
-        const trh_mesh& me = d->meshes[m];
-        if ((uint64_t)me.first_vertex + me.vertex_count > d->vertex_count || (uint64_t)me.first_index + me.index_count > d->index_count)
-            return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: mesh range out of bounds");
-        if (me.material >= d->material_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: mesh material out of range");
-        if (me.index_count / 3 > 0xffffffu) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 2^24 triangles in one mesh");
-        for (uint32_t t = 0; t < me.index_count / 3; ++t) {
-            bvh::InputTriangle it;
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t li = d->indices[me.first_index + t * 3 + k];
-                if (li >= me.vertex_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: vertex index out of range");
-                const float* v = d->vertices + (size_t)(me.first_vertex + li) * TRH_VERTEX_FLOATS;
-                float* dst = k == 0 ? it.v0 : (k == 1 ? it.v1 : it.v2);
-                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
-            }
-            it.packed_id = (m << 24) | t;
-            tris.push_back(it);
-        }
-    }
-    if (tris.size() >= (1u << 27)) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 2^27 triangles");
+    if (int frc = flatten_triangles(d, tris, any_normal_map)) return frc;
 
     // ---- build the BVH on the host
     const auto t0 = std::chrono::steady_clock::now();
@@ -839,6 +848,33 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     c->bvh.tri_bytes = r.tris.size() * 4;
     c->bvh.sah_cost = r.sah_cost;
     c->bvh.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    return TRH_OK;
+}
+
+int trh_bvh_build_host(const trh_scene_desc* d, trh_bvh_info* info_out, uint64_t* hash_out, uint64_t* violations_out) {
+    if (!d || !violations_out) return fail(TRH_ERR_INVALID_ARG, "trh_bvh_build_host: NULL argument");
+    std::vector<bvh::InputTriangle> tris;
+    bool any_normal_map = false;
+    if (int frc = flatten_triangles(d, tris, any_normal_map)) return frc;
+    const auto t0 = std::chrono::steady_clock::now();
+    bvh::Result r;
+    bvh::build(tris, r);
+    const auto t1 = std::chrono::steady_clock::now();
+    std::string why;
+    *violations_out = bvh::validate(tris, r, why, hash_out);
+    if (*violations_out) g_err = "trh_bvh_build_host: " + why;
+    if (info_out) {
+        const bool use_fp16 = r.fp16_inflation <= bvh::kMaxFp16Inflation;
+        info_out->node_count = (uint32_t)(r.nodes.size() / 16);
+        info_out->tri_count = (uint32_t)r.prim_index.size();
+        info_out->max_depth = r.max_depth;
+        info_out->max_leaf_size = r.max_leaf;
+        info_out->node_bytes = use_fp16 ? r.nodes16.size() * 4 : r.nodes.size() * 4;
+        info_out->tri_bytes = r.tris.size() * 4;
+        info_out->sah_cost = r.sah_cost;
+        info_out->build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        info_out->fp16_inflation = r.fp16_inflation;
+    }
     return TRH_OK;
 }
 

@@ -2,10 +2,15 @@
 #include "bvh_builder.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <thread>
 
 namespace bvh {
 namespace {
@@ -38,11 +43,17 @@ constexpr float kCostIntersect = 1.0f;   // one Moller-Trumbore test
 // ---- IEEE binary16 with directed rounding (host only; g++ 11 has no _Float16 on x86)
 float half_to_float(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    const uint32_t em = h & 0x7fffu;
+    uint32_t bits;
     float v;
-    if (e == 0) v = std::ldexp((float)m, -24);
-    else if (e == 31) v = m ? NAN : INFINITY;
-    else v = std::ldexp((float)(m | 1024u), (int)e - 25);
+    if (em >= 0x7c00u) {                       // inf / nan
+        bits = sign | 0x7f800000u | ((em & 0x3ffu) << 13);
+        memcpy(&v, &bits, 4);
+        return v;
+    }
+    bits = em << 13;                           // exponent still biased by 15: scale by 2^(127-15)
+    memcpy(&v, &bits, 4);
+    v *= 0x1p112f;                             // exact; also turns half subnormals into the right floats
     return sign ? -v : v;
 }
 uint16_t half_next_down(uint16_t h) {   // next representable value toward -inf (h finite or +inf)
@@ -53,36 +64,38 @@ uint16_t half_next_up(uint16_t h) {     // toward +inf (h finite or -inf)
     if (h == 0x8000u) return 0x0001u;
     return (h & 0x8000u) ? (uint16_t)(h - 1u) : (uint16_t)(h + 1u);
 }
-uint16_t half_nearest(double v) {       // any rounding will do: the callers fix the direction afterwards
-    if (!(v == v)) return 0x7E00u;
-    const uint16_t sign = std::signbit(v) ? 0x8000u : 0u;
-    double a = std::fabs(v);
-    if (a >= 65520.0) return sign | 0x7C00u;
-    if (a < std::ldexp(1.0, -25)) return sign;
-    int ex;
-    (void)std::frexp(a, &ex);           // a = f * 2^ex, f in [0.5, 1)
-    int e = ex - 1 + 15;                // biased exponent of the leading bit
-    if (e <= 0) {                       // subnormal: units of 2^-24
-        const uint32_t q = (uint32_t)std::lround(std::ldexp(a, 24));
-        return sign | (uint16_t)q;      // q == 1024 rolls over into the smallest normal, as it should
-    }
-    uint32_t q = (uint32_t)std::lround(std::ldexp(a, 10 - (ex - 1)));  // in [1024, 2048]
-    if (q == 2048u) { q = 1024u; ++e; }
-    if (e >= 31) return sign | 0x7C00u;
-    return sign | (uint16_t)((uint32_t)e << 10) | (uint16_t)(q - 1024u);
+uint16_t half_truncate(float f) {       // |result| <= |f| (round toward zero); |f| < 65520 assumed
+    uint32_t bits;
+    memcpy(&bits, &f, 4);
+    const uint16_t sign = (uint16_t)((bits >> 16) & 0x8000u);
+    const uint32_t a = bits & 0x7fffffffu;
+    if (a >= 0x38800000u) return sign | (uint16_t)((a >> 13) - (112u << 10));   // >= 2^-14: normal half
+    float m;
+    memcpy(&m, &a, 4);
+    return sign | (uint16_t)(uint32_t)(m * 0x1p24f);                            // subnormal half: units of 2^-24
 }
-uint16_t half_floor(double v) {         // largest half <= v (v > -65504 assumed; -inf otherwise)
+uint16_t half_floor(double v) {         // largest half <= v
     if (v >= 65504.0) return 0x7BFFu;
     if (v < -65504.0) return 0xFC00u;
-    uint16_t h = half_nearest(v);
+    uint16_t h = half_truncate((float)v);
     while ((double)half_to_float(h) > v) h = half_next_down(h);
+    for (;;) {                          // tighten: (float)v or the truncation may have stepped too far
+        const uint16_t up = half_next_up(h);
+        if (up == 0x7C00u || (double)half_to_float(up) > v) break;
+        h = up;
+    }
     return h;
 }
 uint16_t half_ceil(double v) {          // smallest half >= v
     if (v <= -65504.0) return 0xFBFFu;
     if (v > 65504.0) return 0x7C00u;
-    uint16_t h = half_nearest(v);
+    uint16_t h = half_truncate((float)v);
     while ((double)half_to_float(h) < v) h = half_next_up(h);
+    for (;;) {
+        const uint16_t dn = half_next_down(h);
+        if (dn == 0xFC00u || (double)half_to_float(dn) < v) break;
+        h = dn;
+    }
     return h;
 }
 
@@ -92,36 +105,56 @@ int levels_needed(size_t n) {  // inner-record levels a median-split subtree of 
     return l;
 }
 
+// The tree is first built into temporary records (parallel: sub-ranges of `refs` are independent, so
+// sub-trees are separate tasks and the binning of big nodes is split over threads), then emitted in
+// depth-first pre-order by one thread. The result does not depend on the number of threads: the
+// partitions are deterministic, bin merging is exact (min / max / counts), and the final layout is fixed
+// by the pre-order walk.
+struct TmpNode {
+    Box lb, rb;
+    int c0 = 0, c1 = 0;   // >= 0: temporary record index; < 0: leaf ~((first << 4) | count), first = position in refs
+};
+
 struct Builder {
     const std::vector<InputTriangle>& in;
     std::vector<Ref> refs;
     Result& out;
     float root_area = 1.f;
     float scene_extent = 0.f;
+    std::vector<TmpNode> tmp;
+    std::atomic<int> tmp_next{0};
+    std::atomic<int> spare_threads{0};
+    std::atomic<int> tasks_spawned{0};
+    static constexpr size_t kTaskMin = 8192;       // smaller sub-trees are not worth a task
+    static constexpr size_t kParallelBinMin = 1u << 17;
 
     Builder(const std::vector<InputTriangle>& t, Result& r) : in(t), out(r) {}
 
-    int make_leaf(size_t begin, size_t end, const Box& box) {
-        const uint32_t first = (uint32_t)out.prim_index.size();
-        const uint32_t count = (uint32_t)(end - begin);
-        for (size_t i = begin; i < end; ++i) {
-            const InputTriangle& t = in[refs[i].idx];
-            float rec[12];
-            for (int a = 0; a < 3; ++a) {
-                rec[a] = t.v0[a];
-                rec[4 + a] = t.v1[a] - t.v0[a];  // same subtraction RayTriangle does (collision.h:35-36)
-                rec[8 + a] = t.v2[a] - t.v0[a];
-            }
-            memcpy(&rec[3], &t.packed_id, 4);
-            rec[7] = 0.f;
-            rec[11] = 0.f;
-            out.tris.insert(out.tris.end(), rec, rec + 12);
-            out.prim_index.push_back(refs[i].idx);
+    struct Bins {
+        Box bb[3][kSahBins];
+        uint32_t cnt[3][kSahBins];
+        Bins() { memset(cnt, 0, sizeof(cnt)); }
+        void merge(const Bins& o) {
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < kSahBins; ++b) { bb[a][b].grow(o.bb[a][b]); cnt[a][b] += o.cnt[a][b]; }
         }
-        out.max_leaf = std::max(out.max_leaf, count);
-        out.sah_cost += (double)box.half_area() / root_area * count * kCostIntersect;
-        return ~(int)((first << 4) | count);
+    };
+
+    void bin_range(size_t begin, size_t end, const Box& cb, const bool use_axis[3], Bins& bins) const {
+        float lo[3], scale[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = cb.mn[a]; scale[a] = use_axis[a] ? kSahBins / (cb.mx[a] - cb.mn[a]) : 0.f; }
+        for (size_t i = begin; i < end; ++i) {
+            const Ref& r = refs[i];
+            for (int a = 0; a < 3; ++a) {
+                if (!use_axis[a]) continue;
+                const int b = std::min(kSahBins - 1, std::max(0, (int)((r.c[a] - lo[a]) * scale[a])));
+                bins.bb[a][b].grow(r.box);
+                ++bins.cnt[a][b];
+            }
+        }
     }
+
+    int make_leaf(size_t begin, size_t end) const { return ~(int)(((uint32_t)begin << 4) | (uint32_t)(end - begin)); }
 
     // returns child link; box = bounds of [begin,end)
     int build(size_t begin, size_t end, const Box& box, int depth /* depth of the record this range would become */) {
@@ -133,17 +166,30 @@ struct Builder {
         float best_cost = FLT_MAX;
         int best_axis = -1, best_bin = -1;
         if (n > 1) {
+            bool use_axis[3];
+            for (int a = 0; a < 3; ++a) use_axis[a] = (cb.mx[a] - cb.mn[a]) > 0.f;
+            Bins bins;
+            int helpers = 0;
+            if (n >= kParallelBinMin) {   // big node: split the binning over the spare threads
+                helpers = spare_threads.exchange(0);
+            }
+            if (helpers > 0) {
+                const int parts = helpers + 1;
+                std::vector<Bins> part((size_t)parts);
+                std::vector<std::future<void>> fut;
+                for (int t = 1; t < parts; ++t)
+                    fut.push_back(std::async(std::launch::async, [&, t]() { bin_range(begin + n * t / parts, begin + n * (t + 1) / parts, cb, use_axis, part[t]); }));
+                bin_range(begin, begin + n / parts, cb, use_axis, part[0]);
+                for (auto& f : fut) f.get();
+                for (int t = 0; t < parts; ++t) bins.merge(part[t]);
+                spare_threads.fetch_add(helpers);
+            } else {
+                bin_range(begin, end, cb, use_axis, bins);
+            }
             for (int axis = 0; axis < 3; ++axis) {
-                const float lo = cb.mn[axis], ext = cb.mx[axis] - cb.mn[axis];
-                if (!(ext > 0.f)) continue;
-                Box bb[kSahBins];
-                uint32_t cnt[kSahBins] = {0};
-                const float scale = kSahBins / ext;
-                for (size_t i = begin; i < end; ++i) {
-                    int b = std::min(kSahBins - 1, std::max(0, (int)((refs[i].c[axis] - lo) * scale)));
-                    bb[b].grow(refs[i].box);
-                    ++cnt[b];
-                }
+                if (!use_axis[axis]) continue;
+                const Box* bb = bins.bb[axis];
+                const uint32_t* cnt = bins.cnt[axis];
                 float right_area[kSahBins];
                 uint32_t right_cnt[kSahBins];
                 Box acc;
@@ -168,7 +214,7 @@ struct Builder {
         const float parent_area = std::max(box.half_area(), 1e-30f);
         const float split_cost = kCostTraverse + kCostIntersect * best_cost / parent_area;
         const float leaf_cost = kCostIntersect * (float)n;
-        if (n <= (size_t)kMaxLeafSize && (best_axis < 0 || leaf_cost <= split_cost || n == 1 || depth > kMaxDepth)) return make_leaf(begin, end, box);
+        if (n <= (size_t)kMaxLeafSize && (best_axis < 0 || leaf_cost <= split_cost || n == 1 || depth > kMaxDepth)) return make_leaf(begin, end);
 
         // --- partition
         size_t mid = begin;
@@ -197,14 +243,67 @@ struct Builder {
         for (size_t i = begin; i < mid; ++i) lb.grow(refs[i].box);
         for (size_t i = mid; i < end; ++i) rb.grow(refs[i].box);
 
+        const int me = tmp_next.fetch_add(1);
+        TmpNode& node = tmp[(size_t)me];
+        node.lb = lb;
+        node.rb = rb;
+        // the left sub-tree becomes a task if it is big enough and a thread is spare
+        bool spawned = false;
+        std::future<int> left;
+        if (mid - begin >= kTaskMin && end - mid >= kTaskMin) {
+            int s = spare_threads.load();
+            while (s > 0 && !spare_threads.compare_exchange_weak(s, s - 1)) {}
+            if (s > 0) {
+                spawned = true;
+                tasks_spawned.fetch_add(1);
+                left = std::async(std::launch::async, [this, begin, mid, lb, depth]() { return build(begin, mid, lb, depth + 1); });
+            }
+        }
+        if (!spawned) node.c0 = build(begin, mid, lb, depth + 1);
+        node.c1 = build(mid, end, rb, depth + 1);
+        if (spawned) {
+            node.c0 = left.get();
+            spare_threads.fetch_add(1);
+        }
+        return me;
+    }
+
+    // depth-first pre-order emission of the final records (the layout the sequential recursion produced)
+    int emit(int link, const Box& box, int depth) {
+        if (link < 0) {
+            const uint32_t bits = ~(uint32_t)link;
+            const uint32_t count = bits & 15u;
+            out.max_leaf = std::max(out.max_leaf, count);
+            out.sah_cost += (double)box.half_area() / root_area * count * kCostIntersect;
+            return link;
+        }
+        const TmpNode& t = tmp[(size_t)link];
         const int me = (int)(out.nodes.size() / 16);
         out.nodes.resize(out.nodes.size() + 16, 0.f);
         out.max_depth = std::max(out.max_depth, (uint32_t)depth);
         out.sah_cost += (double)box.half_area() / root_area * kCostTraverse;
-        const int c0 = build(begin, mid, lb, depth + 1);
-        const int c1 = build(mid, end, rb, depth + 1);
-        write_record(me, lb, rb, c0, c1);
+        const int c0 = emit(t.c0, t.lb, depth + 1);
+        const int c1 = emit(t.c1, t.rb, depth + 1);
+        write_record(me, t.lb, t.rb, c0, c1);
         return me;
+    }
+
+    void write_triangles() {
+        out.tris.resize(refs.size() * 12);
+        out.prim_index.resize(refs.size());
+        for (size_t i = 0; i < refs.size(); ++i) {
+            const InputTriangle& t = in[refs[i].idx];
+            float* rec = &out.tris[i * 12];
+            for (int a = 0; a < 3; ++a) {
+                rec[a] = t.v0[a];
+                rec[4 + a] = t.v1[a] - t.v0[a];  // same subtraction RayTriangle does (collision.h:35-36)
+                rec[8 + a] = t.v2[a] - t.v0[a];
+            }
+            memcpy(&rec[3], &t.packed_id, 4);
+            rec[7] = 0.f;
+            rec[11] = 0.f;
+            out.prim_index[i] = refs[i].idx;
+        }
     }
 
     void pad(Box& b) const {
@@ -262,33 +361,53 @@ struct Builder {
         for (int a = 0; a < 3; ++a) out.frame_center[a] = (float)c[a];
         out.frame_scale = (float)s;
         out.nodes16.assign(n * 8, 0u);
-        double area_exact = 0.0, area_quant = 0.0;
         auto half_area = [](double dx, double dy, double dz) { return (dx < 0 || dy < 0 || dz < 0) ? 0.0 : dx * dy + dy * dz + dz * dx; };
-        for (size_t i = 0; i < n; ++i) {
-            const float* r = &out.nodes[i * 16];
-            uint32_t* q = &out.nodes16[i * 8];
-            auto pack = [&](float mn, float mx, int axis) {
-                const double cc = (double)out.frame_center[axis];   // the float the kernel subtracts
-                const uint16_t lo = half_floor(((double)mn - cc) * s);
-                const uint16_t hi = half_ceil(((double)mx - cc) * s);
-                return (uint32_t)lo | ((uint32_t)hi << 16);
-            };
-            q[0] = pack(r[0], r[1], 0);  q[1] = pack(r[2], r[3], 1);
-            q[2] = pack(r[4], r[5], 0);  q[3] = pack(r[6], r[7], 1);
-            q[4] = pack(r[8], r[9], 2);  q[5] = pack(r[10], r[11], 2);
-            memcpy(&q[6], &r[12], 4);
-            memcpy(&q[7], &r[13], 4);
-            // inflation measure (boxes of empty / padding leaves are skipped: |bound| >= 1e30)
-            const int ex[2][6] = {{0, 1, 2, 3, 8, 9}, {4, 5, 6, 7, 10, 11}};   // minx maxx miny maxy minz maxz in r[]
-            const int qx[2][3] = {{0, 1, 4}, {2, 3, 5}};                        // words holding x, y, z (min | max << 16)
-            for (int c = 0; c < 2; ++c) {
-                if (std::fabs(r[ex[c][0]]) >= 1e30f) continue;
-                area_exact += half_area((double)r[ex[c][1]] - r[ex[c][0]], (double)r[ex[c][3]] - r[ex[c][2]], (double)r[ex[c][5]] - r[ex[c][4]]);
-                double d[3];
-                for (int a = 0; a < 3; ++a) d[a] = ((double)half_to_float((uint16_t)(q[qx[c][a]] >> 16)) - (double)half_to_float((uint16_t)(q[qx[c][a]] & 0xffffu))) / s;
-                area_quant += half_area(d[0], d[1], d[2]);
+        // a fixed number of chunks (independent of the thread count) so that the area sums do not depend on it
+        constexpr size_t kChunks = 64;
+        double exact_part[kChunks] = {0}, quant_part[kChunks] = {0};
+        auto do_chunk = [&](size_t ch) {
+            double area_exact = 0.0, area_quant = 0.0;
+            for (size_t i = n * ch / kChunks; i < n * (ch + 1) / kChunks; ++i) {
+                const float* r = &out.nodes[i * 16];
+                uint32_t* q = &out.nodes16[i * 8];
+                auto pack = [&](float mn, float mx, int axis) {
+                    const double cc = (double)out.frame_center[axis];   // the float the kernel subtracts
+                    const uint16_t lo = half_floor(((double)mn - cc) * s);
+                    const uint16_t hi = half_ceil(((double)mx - cc) * s);
+                    return (uint32_t)lo | ((uint32_t)hi << 16);
+                };
+                q[0] = pack(r[0], r[1], 0);  q[1] = pack(r[2], r[3], 1);
+                q[2] = pack(r[4], r[5], 0);  q[3] = pack(r[6], r[7], 1);
+                q[4] = pack(r[8], r[9], 2);  q[5] = pack(r[10], r[11], 2);
+                memcpy(&q[6], &r[12], 4);
+                memcpy(&q[7], &r[13], 4);
+                // inflation measure (boxes of empty / padding leaves are skipped: |bound| >= 1e30)
+                const int ex[2][6] = {{0, 1, 2, 3, 8, 9}, {4, 5, 6, 7, 10, 11}};   // minx maxx miny maxy minz maxz in r[]
+                const int qx[2][3] = {{0, 1, 4}, {2, 3, 5}};                        // words holding x, y, z (min | max << 16)
+                for (int c = 0; c < 2; ++c) {
+                    if (std::fabs(r[ex[c][0]]) >= 1e30f) continue;
+                    area_exact += half_area((double)r[ex[c][1]] - r[ex[c][0]], (double)r[ex[c][3]] - r[ex[c][2]], (double)r[ex[c][5]] - r[ex[c][4]]);
+                    double d[3];
+                    for (int a = 0; a < 3; ++a) d[a] = ((double)half_to_float((uint16_t)(q[qx[c][a]] >> 16)) - (double)half_to_float((uint16_t)(q[qx[c][a]] & 0xffffu))) / s;
+                    area_quant += half_area(d[0], d[1], d[2]);
+                }
             }
+            exact_part[ch] = area_exact;
+            quant_part[ch] = area_quant;
+        };
+        {
+            int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            if (const char* e = getenv("TRH_BUILD_THREADS")) threads = std::max(1, atoi(e));
+            if (n < 65536) threads = 1;
+            std::atomic<size_t> next_chunk{0};
+            auto worker = [&]() { for (size_t ch; (ch = next_chunk.fetch_add(1)) < kChunks;) do_chunk(ch); };
+            std::vector<std::future<void>> fut;
+            for (int t = 1; t < threads; ++t) fut.push_back(std::async(std::launch::async, worker));
+            worker();
+            for (auto& f : fut) f.get();
         }
+        double area_exact = 0.0, area_quant = 0.0;
+        for (size_t ch = 0; ch < kChunks; ++ch) { area_exact += exact_part[ch]; area_quant += quant_part[ch]; }
         out.fp16_inflation = area_exact > 0.0 ? area_quant / area_exact : 1.0;
     }
 
@@ -310,24 +429,36 @@ struct Builder {
         out.nodes.clear();
         out.tris.clear();
         out.prim_index.clear();
-        out.tris.reserve(in.size() * 12);
-        out.prim_index.reserve(in.size());
         const int empty_leaf = ~(1 << 4);  // first 1, count 0 (never -1: the kernels read a link of -1 as "nothing to traverse")
         if (in.empty()) {
             out.nodes.resize(16, 0.f);
             write_record(0, Box{}, Box{}, empty_leaf, empty_leaf);
             return;
         }
-        int root = build(0, in.size(), all, 1);
+        int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = getenv("TRH_BUILD_THREADS")) threads = std::max(1, atoi(e));
+        spare_threads.store(threads - 1);
+        tmp.resize(std::max<size_t>(in.size(), 1));
+        const auto tb0 = std::chrono::steady_clock::now();
+        const int root = build(0, in.size(), all, 1);
+        if (getenv("TRH_VERBOSE"))
+            fprintf(stderr, "bvh::build: %d threads, recursion %.1f ms, %d tasks\n", threads,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), tasks_spawned.load());
+        out.nodes.reserve((size_t)tmp_next.load() * 16 + 16);
         if (root < 0) {
             // the whole scene fits one leaf: wrap it in a root record (traversal always starts at record 0)
             out.nodes.resize(16, 0.f);
             Box none;
             none.mn[0] = none.mn[1] = none.mn[2] = 0.f;
             none.mx[0] = none.mx[1] = none.mx[2] = 0.f;
+            out.max_leaf = (uint32_t)in.size();
+            out.sah_cost = (double)in.size() * kCostIntersect;
             write_record(0, all, none, root, empty_leaf);
             out.max_depth = 1;
+        } else {
+            emit(root, all, 1);
         }
+        write_triangles();
     }
 };
 
@@ -337,8 +468,96 @@ void build(const std::vector<InputTriangle>& tris, Result& out) {
     out = Result{};
     if (const char* e = getenv("TRH_SAH_CT")) { const float v = (float)atof(e); if (v > 0.f) kCostTraverse = v; }   // development knob
     Builder b(tris, out);
+    const auto t0 = std::chrono::steady_clock::now();
     b.run();
+    const auto t1 = std::chrono::steady_clock::now();
     b.quantise();
+    const auto t2 = std::chrono::steady_clock::now();
+    if (getenv("TRH_VERBOSE"))
+        fprintf(stderr, "bvh::build: %zu triangles, tree %.1f ms, fp16 records %.1f ms\n", tris.size(),
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+}
+
+uint64_t validate(const std::vector<InputTriangle>& tris, const Result& r, std::string& first, uint64_t* hash_out) {
+    uint64_t bad = 0;
+    auto fail = [&](const std::string& what) { if (bad++ == 0) first = what; };
+    const size_t n_nodes = r.nodes.size() / 16, n_prims = r.prim_index.size();
+    if (r.nodes16.size() != n_nodes * 8) fail("nodes16 size");
+    if (r.tris.size() != n_prims * 12 || n_prims != tris.size()) fail("triangle array size");
+    std::vector<uint8_t> seen_prim(tris.size(), 0), seen_leaf_pos(n_prims, 0), seen_node(n_nodes, 0);
+    for (uint32_t p : r.prim_index) {
+        if (p >= tris.size()) { fail("prim_index out of range"); continue; }
+        if (seen_prim[p]++) fail("triangle stored twice");
+    }
+    for (size_t i = 0; i < tris.size(); ++i) if (!seen_prim[i]) { fail("triangle missing from the tree"); break; }
+    const double s = r.frame_scale;
+    struct Item { int node; int depth; };
+    std::vector<Item> todo;
+    if (n_nodes) todo.push_back({0, 1});
+    uint32_t max_depth = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.node < 0 || (size_t)it.node >= n_nodes) { fail("child link out of range"); continue; }
+        if (seen_node[(size_t)it.node]++) { fail("record reachable twice"); continue; }
+        max_depth = std::max(max_depth, (uint32_t)it.depth);
+        const float* f = &r.nodes[(size_t)it.node * 16];
+        const uint32_t* q = &r.nodes16[(size_t)it.node * 8];
+        const int fi[2][6] = {{0, 1, 2, 3, 8, 9}, {4, 5, 6, 7, 10, 11}};
+        const int qi[2][3] = {{0, 1, 4}, {2, 3, 5}};
+        for (int c = 0; c < 2; ++c) {
+            int link;
+            memcpy(&link, &f[12 + c], 4);
+            int link16;
+            memcpy(&link16, &q[6 + c], 4);
+            if (link != link16) fail("fp16 record link differs from the fp32 record");
+            if (link == -1) fail("link -1 is reserved");
+            const bool sentinel = std::fabs(f[fi[c][0]]) >= 1e30f;
+            if (!sentinel) {
+                for (int a = 0; a < 3; ++a) {
+                    // containment in the frame the kernel works in: x' = (x - c) * s with the float centre c
+                    const double lo = (double)half_to_float((uint16_t)(q[qi[c][a]] & 0xffffu)), hi = (double)half_to_float((uint16_t)(q[qi[c][a]] >> 16));
+                    const double flo = ((double)f[fi[c][2 * a]] - (double)r.frame_center[a]) * s, fhi = ((double)f[fi[c][2 * a + 1]] - (double)r.frame_center[a]) * s;
+                    if (lo > flo || hi < fhi) fail("fp16 box does not contain the fp32 box");
+                }
+            }
+            if (link >= 0) {
+                todo.push_back({link, it.depth + 1});
+            } else {
+                const uint32_t bits = ~(uint32_t)link, first_p = bits >> 4, count = bits & 15u;
+                if (count > (uint32_t)kMaxLeafSize) fail("leaf larger than kMaxLeafSize");
+                for (uint32_t k = 0; k < count; ++k) {
+                    const size_t pos = (size_t)first_p + k;
+                    if (pos >= n_prims) { fail("leaf range out of bounds"); break; }
+                    if (seen_leaf_pos[pos]++) fail("leaf ranges overlap");
+                    const InputTriangle& t = tris[r.prim_index[pos]];
+                    const float* vs[3] = {t.v0, t.v1, t.v2};
+                    for (const float* v : vs)
+                        for (int a = 0; a < 3; ++a)
+                            if (v[a] < f[fi[c][2 * a]] || v[a] > f[fi[c][2 * a + 1]]) fail("leaf box does not contain its triangle");
+                    uint32_t id;
+                    memcpy(&id, &r.tris[pos * 12 + 3], 4);
+                    if (id != t.packed_id) fail("triangle record id mismatch");
+                }
+            }
+        }
+    }
+    for (size_t i = 0; i < n_prims; ++i) if (!seen_leaf_pos[i]) { fail("triangle slot not covered by a leaf"); break; }
+    for (size_t i = 0; i < n_nodes; ++i) if (!seen_node[i]) { fail("record unreachable"); break; }
+    if (max_depth > (uint32_t)kMaxDepth) fail("tree deeper than kMaxDepth");
+    if (max_depth != r.max_depth && !tris.empty()) fail("max_depth field wrong");
+    if (hash_out) {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](const void* p, size_t bytes) {
+            const uint8_t* b = (const uint8_t*)p;
+            for (size_t i = 0; i < bytes; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+        };
+        mix(r.nodes.data(), r.nodes.size() * 4);
+        mix(r.nodes16.data(), r.nodes16.size() * 4);
+        mix(r.tris.data(), r.tris.size() * 4);
+        *hash_out = h;
+    }
+    return bad;
 }
 
 }  // namespace bvh

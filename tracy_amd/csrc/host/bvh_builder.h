@@ -9,6 +9,7 @@
 // records (v0, e1, e2 + packed reference id).
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace bvh {
@@ -58,5 +59,12 @@ struct Result {
 };
 
 void build(const std::vector<InputTriangle>& tris, Result& out);
+
+// Structural self-check of a build result (host only, used by trh_bvh_build_host and the CPU tests):
+// every triangle in exactly one leaf, every leaf box contains its triangles' vertices, every fp16 box
+// contains the fp32 box it was rounded from, depth / leaf size / link encoding within the documented
+// limits, every record reachable exactly once. Returns the number of violations (0 = sound) and a text
+// for the first one. hash_out: FNV-1a over the three arrays (layout determinism across thread counts).
+uint64_t validate(const std::vector<InputTriangle>& tris, const Result& r, std::string& first_violation, uint64_t* hash_out);
 
 }  // namespace bvh
