@@ -132,7 +132,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, Re
 // per lane) + 4 waves x P x 3 floats (tile accumulators).
 // ---------------------------------------------------------------------------------------
 #ifndef TRH_INNER_REPEAT
-#define TRH_INNER_REPEAT 2
+#define TRH_INNER_REPEAT 3
 #endif
 #ifndef TRH_MEGA_WAVES_PER_EU
 #define TRH_MEGA_WAVES_PER_EU 4
