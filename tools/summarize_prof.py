@@ -38,7 +38,7 @@ json.dump(out, open(os.path.join(d, "pmc_avg.json"), "w"), indent=1)
 # HBM-side traffic per launch of the render kernel for bench.py's roofline.traffic: FETCH_SIZE / WRITE_SIZE are
 # in KiB; gfx950 reports half the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, "HBM"), so reads are doubled.
 for k, cs in out.items():
-    if "megakernel<false>" in k.replace(" ", "") and "FETCH_SIZE" in cs:
+    if "megakernel<false" in k.replace(" ", "") and "FETCH_SIZE" in cs:
         traffic = cs["FETCH_SIZE"] * 1024 * 2 + cs.get("WRITE_SIZE", 0.0) * 1024
         print(f"\nHBM-side traffic per launch (2 x FETCH_SIZE + WRITE_SIZE): {traffic/1e9:.3f} GB")
         json.dump({"traffic_bytes_per_launch": traffic, "kernel": k[:80]}, open(os.path.join(d, "traffic.json"), "w"))
