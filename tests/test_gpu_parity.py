@@ -330,3 +330,111 @@ def test_both_record_formats_render_the_same_dragon(scene_loader, monkeypatch):
         mod.Shutdown()
     assert out["16"][1] == out["32"][1]                    # identical ray counts: identical paths
     assert np.allclose(out["16"][0], out["32"][0], rtol=2e-6, atol=1e-7)   # summation order follows the schedule
+
+
+# ----------------------------------------------------------------------------- edge cases
+def _scene_from_text(tmp_path, text, name="edge.scn"):
+    from tracy_amd import Scene
+    p = tmp_path / name
+    p.write_text(text)
+    return Scene(str(p))
+
+
+def test_empty_scene_is_all_sky(tmp_path, oracle_mod):
+    """No geometry at all: every path is one miss ray and the image is the constant sky emission."""
+    from tracy_amd import HipTrace
+    sc = _scene_from_text(tmp_path, "SCN empty\nOUT 40 24\nCAM (0,0,5) (0,0,0) (0,1,0) 45\nSKY (0.25,0.5,0.75)\n")
+    assert sc.tri_count == 0
+    mod = HipTrace()
+    mod.Startup(sc)
+    try:
+        ids, t, _ = mod.primary_hits()
+        assert (ids == MISS).all()
+        mod.render(0, 9)
+        img, n = mod.resolve()
+        assert n == 9 and mod.stats()["rays"] == 40 * 24 * 9
+        assert np.allclose(img[..., :3], [0.25, 0.5, 0.75], rtol=1e-6)
+        ref = oracle_mod.CpuRef(sc)
+        ref.render(0, 9)
+        assert np.allclose(img[..., :3], ref.output(), rtol=1e-6)
+    finally:
+        mod.Shutdown()
+
+
+def test_single_triangle_and_back_face_culling(tmp_path, oracle_mod):
+    """One triangle seen from the front, then from behind (collision.h:44 culls det < EPS): ids, t, uv
+    and a few samples must equal the oracle's in both views."""
+    from tracy_amd import HipTrace
+    text = ("SCN tri\nOUT 48 32\nCAM (0,0,{z}) (0,0,0) (0,1,0) 50\nSKY (1,1,1)\nMTL m (0.8,0.3,0.2) 1 0\n"
+            "OBJ T (-1,-1,0) (1,-1,0) (0,1,0) m\n")
+    for z, expect_hits in ((3, True), (-3, False)):
+        sc = _scene_from_text(tmp_path, text.format(z=z), f"tri{z}.scn")
+        assert sc.tri_count == 1
+        mod = HipTrace()
+        mod.Startup(sc)
+        try:
+            ref = oracle_mod.CpuRef(sc)
+            ids, t, uv = mod.primary_hits()
+            rids, rt, ruv = ref.primary_hits()
+            assert np.array_equal(ids, rids)
+            assert ((ids != MISS).any()) == expect_hits
+            hit = ids != MISS
+            assert np.array_equal(t[hit], rt[hit]) and np.array_equal(uv[hit], ruv[hit])
+            for s in (0, 3):
+                a, b = mod.sample_radiance(s), ref.sample_radiance(s)
+                assert np.array_equal(a[..., 3], b[..., 3])
+                assert np.allclose(a[..., :3], b[..., :3], rtol=1e-4, atol=1e-5)
+        finally:
+            mod.Shutdown()
+
+
+def test_degenerate_triangles_do_not_disturb_the_render(tmp_path, oracle_mod):
+    """Zero-area triangles (a collapsed box face, dragon.scn:56 has such a floor) and a needle are legal
+    input: det = 0 rejects them in RayTriangle; the BVH must still be sound and the hits the oracle's."""
+    from tracy_amd import HipTrace
+    sc = _scene_from_text(tmp_path, "SCN degenerate\nOUT 64 36\nCAM (0,2,6) (0,0.5,0) (0,1,0) 45\nSKY (0.5,0.6,0.8)\n"
+                          "MTL grey (0.5,0.5,0.5) 1 0\nMTL red (0.8,0.1,0.1) 0.3 0.5\n"
+                          "OBJ B (-5,0,-5) (5,0,5) grey\n"                 # flat box: two coincident quads + four zero-area sides
+                          "OBJ T (0,0.5,0) (0,0.5,0) (0,0.5,0) red\n"      # a point
+                          "OBJ T (-1,0.2,0) (1,0.2,0) (3,0.2,0) red\n"     # a needle (collinear)
+                          "OBJ S (0,1,0) 0.7 red\n")
+    mod = HipTrace()
+    mod.Startup(sc)
+    try:
+        ref = oracle_mod.CpuRef(sc)
+        ids, t, _ = mod.primary_hits()
+        rids, rt, _ = ref.primary_hits()
+        assert (ids == rids).mean() >= 0.9999
+        mod.render(0, 16)
+        ref.render(0, 16)
+        img, _ = mod.resolve()
+        assert np.isfinite(img).all()
+        assert psnr(img[..., :3], ref.output()) >= 40.0
+        assert mod.stats()["rays"] == ref.counters()["rays"]
+    finally:
+        mod.Shutdown()
+
+
+def test_seed_and_sample_index_define_the_sample_set(hip, scene_loader):
+    """RNG state = f(pixel, global sample index, seed): the same (index, seed) gives the same radiance
+    whatever was rendered before; another seed or index gives another sample."""
+    sc = scene_loader("cornell", 64, 36)
+    mod = hip(sc)
+    a = mod.sample_radiance(7, seed=0xABCDEF)
+    mod.render(0, 5)
+    b = mod.sample_radiance(7, seed=0xABCDEF)
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, mod.sample_radiance(8, seed=0xABCDEF))
+    assert not np.array_equal(a, mod.sample_radiance(7, seed=0x1234567))
+    hi = mod.sample_radiance(7, seed=(1 << 40) | 0xABCDEF)          # the high seed word takes part
+    assert not np.array_equal(a, hi)
+    # accumulating samples one by one or in one launch: the same sample set (summation order aside)
+    mod.reset()
+    for s in range(6):
+        mod.render(s, 1)
+    one_by_one, n1 = mod.resolve()
+    mod.reset()
+    mod.render(0, 6)
+    at_once, n2 = mod.resolve()
+    assert n1 == n2 == 6
+    assert np.allclose(one_by_one, at_once, rtol=2e-6, atol=1e-7)
