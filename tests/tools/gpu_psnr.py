@@ -1,7 +1,7 @@
 """Development aid: PSNR / per-sample agreement of the HIP module vs the oracle per scene."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tracy_amd import Scene, HipTrace
 from oracle.oracle import CpuRef
 

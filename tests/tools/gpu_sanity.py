@@ -1,7 +1,7 @@
 """Quick GPU sanity run (development aid): parity vs the oracle at small size + a timing at 1080p."""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tracy_amd import Scene, HipTrace
 from oracle.oracle import CpuRef
 

@@ -3,7 +3,7 @@ workload statistics from the instrumented kernel (n_box, n_tri, hit f
 sample -> workload/<scene>.json), and parity against the oracle at the config's resolution
 (primary-hit ids; PSNR of a 16-spp image after the build-owned sRGB tonemap).
 
-    python tools/run_configs.py [out.json]          (needs a GPU; the oracle legs run on the host cores)
+    python tests/tools/run_configs.py [out.json]          (needs a GPU; the oracle legs run on the host cores)
 """
 import json
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tracy_amd import Scene, HipTrace  # noqa: E402
 from oracle.oracle import CpuRef  # noqa: E402  (checker only)

@@ -1,11 +1,10 @@
 """Build recipes for the native libraries (in-tree, gfx950 only).
 
     python -m tracy_amd.build            # everything
-    python -m tracy_amd.build hip scene oracle
+    python -m tracy_amd.build hip scene cli
 
 libtracy_scene.so : g++   host scene loader            (include/tracy_scene.h)
 libtracy_hip.so   : hipcc kernels + C ABI + BVH build  (include/tracy_hip.h)
-oracle/liboracle_cpu_ref.so : the CPU oracle (test infrastructure), via oracle/Makefile
 """
 import os
 import subprocess
@@ -74,22 +73,14 @@ def build_cli(force=False):
     return out
 
 
-def build_oracle(force=False):
-    if force:
-        _run(["make", "-C", os.path.join(ROOT, "oracle"), "clean"])
-    _run(["make", "-C", os.path.join(ROOT, "oracle")])
-    return os.path.join(ROOT, "oracle", "liboracle_cpu_ref.so")
-
-
 def build_all(force=False):
     build_scene(force)
     build_hip(force)
     build_cli(force)
-    build_oracle(force)
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["scene", "hip", "cli", "oracle"]
+    what = sys.argv[1:] or ["scene", "hip", "cli"]
     force = "--force" in what
     for w in what:
         if w == "scene":
@@ -98,5 +89,3 @@ if __name__ == "__main__":
             build_hip(force)
         elif w == "cli":
             build_cli(force)
-        elif w == "oracle":
-            build_oracle(force)
