@@ -438,3 +438,34 @@ def test_seed_and_sample_index_define_the_sample_set(hip, scene_loader):
     at_once, n2 = mod.resolve()
     assert n1 == n2 == 6
     assert np.allclose(one_by_one, at_once, rtol=2e-6, atol=1e-7)
+
+
+def test_dragon_against_the_reference_screenshot(scene_loader):
+    """The only output of the real reference that exists for this path: doc/dragon.jpg, a screenshot of
+    the CPU module's window ('Stanford Dragon' 1024x768, [3 objs] [100024 tris], ~100 accumulated frames,
+    build options and commit unknown), kept as tests/golden/reference_doc_dragon.jpg. A loose end-to-end
+    pin of scene loading, camera, materials and tonemap together: after removing the window frame and
+    blurring away the Monte-Carlo noise of both pictures, PSNR >= 20 dB (measured 22.7 dB; the module's
+    picture is ~1.2x brighter in display space)."""
+    from PIL import Image, ImageFilter
+    from tracy_amd import HipTrace
+    shot = Image.open(os.path.join(GOLDEN, "reference_doc_dragon.jpg")).convert("RGB")
+    assert shot.size == (1026, 800)
+    shot = shot.crop((1, 31, 1025, 799))                     # 1 px border, 30 px title bar
+    sc = scene_loader("dragon", 0, 0)                        # OUT 1024 768 from the .scn, as in the screenshot
+    assert (sc.width, sc.height) == (1024, 768)
+    mod = HipTrace()
+    mod.Startup(sc)
+    try:
+        mod.render(0, 256)
+        pic = mod.present()                                  # default build: sRGB tonemap, exposure 1
+    finally:
+        mod.Shutdown()
+    rgb = np.stack([(pic >> 16) & 255, (pic >> 8) & 255, pic & 255], axis=-1).astype(np.uint8)
+    a = np.asarray(Image.fromarray(rgb).filter(ImageFilter.GaussianBlur(4)), dtype=np.float64) / 255
+    b = np.asarray(shot.filter(ImageFilter.GaussianBlur(4)), dtype=np.float64) / 255
+    mse = np.mean((a - b) ** 2)
+    assert 10 * np.log10(1 / mse) >= 20.0
+    # the black sky and the silhouette must coincide: camera and geometry are the same
+    sky_a, sky_b = a.mean(axis=-1) < 0.02, b.mean(axis=-1) < 0.02
+    assert (sky_a == sky_b).mean() >= 0.98
