@@ -8,12 +8,13 @@
 //   Material::Scatter + getters src/material.h:125-268
 //   Texture::GetPixel           src/texture.h:50-57
 //   sky lookup + RR             cpu_trace.cpp:146-166
-// The traversal itself (stack walk over this module's own 64-byte BVH2 records) has no
+// The traversal itself (stack walk over this module's own BVH2 records, bvh_builder.h) has no
 // counterpart in the reference: it replaces accel::IntersectsWithTree (src/kdtree.h:382-429).
 //
 // Arithmetic contract (DESIGN.md "Decreed arithmetic"): this file is compiled with
 // -ffp-contract=off; every fused multiply-add is an explicit __builtin_fmaf and appears only in
-// dot_f/cross_f (RayTriangle). Division and sqrt are IEEE (hipcc default).
+// dot_f/cross_f (RayTriangle) and in the slab distances of the conservative box tests. Division and
+// sqrt are IEEE (hipcc default); the only approximate reciprocal (v_rcp_f32) feeds the box tests.
 #pragma once
 #include "dev_types.h"
 

@@ -1,14 +1,19 @@
 // tracy_hip.hip -- gfx950 kernels and the C ABI of include/tracy_hip.h.
 //
-// Kernels (all hand-written HIP for CDNA4, wave64):
-//   k_megakernel<STATS, N16>   persistent waves pull 8x8-pixel tiles; every lane owns one pixel and
-//                         regenerates its next sample in place as soon as its path ends, so the
-//                         traversal loop stays full until the tile's samples run out.
-//   k_primary_hits        parity probe (a): nearest hit of un-jittered pixel-centre rays.
-//   k_sample_radiance     parity probe (b): radiance of one sample index per pixel.
-//   k_resolve             mean = sum / count (CPUDetails::UpdateOutput, cpu_details.cpp:187-199).
-// Traversal stacks live in LDS (32 entries x 256 lanes x 4 B = 32 KiB per workgroup), column
-// per lane so that ds_read/ds_write_b32 are bank-conflict free at any stack depth.
+// Kernels (all hand-written HIP for CDNA4, wave64; STATS = instrumented build, N16 = 32-byte fp16
+// node records instead of the 64-byte fp32 fallback):
+//   k_megakernel<STATS, N16>         default pipeline: persistent waves pull tiles (8x8 pixels x S samples);
+//                                    lanes are not bound to pixels, a wave-local scheduler hands the tile's
+//                                    camera paths to lanes as they fall idle and votes between inner-node
+//                                    steps and triangle steps (see the comment at the kernel).
+//   k_megakernel_simple<STATS, N16>  first-generation kernel (lane == pixel), kept for A/B measurements.
+//   wavefront.h                      generate / extend / shade / accumulate pipeline with queues in HBM.
+//   k_primary_hits<N16>              parity probe (a): nearest hit of un-jittered pixel-centre rays.
+//   k_sample_radiance<N16>           parity probe (b): radiance of one sample index per pixel.
+//   k_resolve                        mean = sum / count (CPUDetails::UpdateOutput, cpu_details.cpp:187-199).
+//   k_present                        tonemap + BGRA8 picture (CPUDetails::Tonemap/UpdateBitmap, :201-243).
+// Traversal stacks live in LDS, one column per lane (entry i at stack[i * 256]) so that
+// ds_read/ds_write_b32 are bank-conflict free at any depth; the megakernel sizes them to the tree's depth.
 #include "../../../include/tracy_hip.h"
 #include "../host/bvh_builder.h"
 #include "dev_trace.h"
