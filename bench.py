@@ -56,7 +56,7 @@ def cpu_baseline(scene_name, width, height, budget_s=12.0):
     t0 = time.time()
     ref.render(0, 1)
     first = time.time() - t0
-    n = int(max(1, min(32, budget_s / max(first, 1e-3))))
+    n = int(max(1, min(256, budget_s / max(first, 1e-3))))
     ref.counters(reset=True)
     t0 = time.time()
     ref.render(1, n)
