@@ -469,3 +469,43 @@ def test_dragon_against_the_reference_screenshot(scene_loader):
     # the black sky and the silhouette must coincide: camera and geometry are the same
     sky_a, sky_b = a.mean(axis=-1) < 0.02, b.mean(axis=-1) < 0.02
     assert (sky_a == sky_b).mean() >= 0.98
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_random_cameras_against_oracle(oracle_mod, scene_loader, name):
+    """Cameras drawn from deep inside the geometry to well outside it, arbitrary orientation and roll
+    (tests/tools/fuzz_cameras.py runs the long version: 0 id mismatches in 3.24 M pixels): primary-hit ids
+    >= 99.99 % equal, t/u/v bit-equal on equal ids, one sample index of radiance within tolerance."""
+    from tracy_amd import HipTrace, Scene
+    rng = np.random.default_rng(sum(map(ord, name)))
+    sc = Scene(f"data/scenes/{name}.scn", 96, 54)      # private copy: the test moves its camera
+    v = sc.vertices()[:, :3]
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    ctr, ext = (lo + hi) / 2, float(np.max(hi - lo))
+    mod = HipTrace()
+    mod.Startup(sc)
+    ref = oracle_mod.CpuRef(sc)
+    try:
+        bad = outliers = 0
+        cams = 6
+        for _ in range(cams):
+            r = ext * (0.05 + 1.5 * rng.random())
+            eye = ctr + r * rng.normal(size=3) / np.sqrt(3)
+            target = ctr + 0.3 * ext * (rng.random(3) - 0.5)
+            sc.set_view(eye.astype(np.float32), target.astype(np.float32), rng.normal(size=3).astype(np.float32))
+            e, ivp = sc.eye_ivp()
+            mod.set_camera(e, ivp)
+            ref.set_camera(e, ivp)
+            ids, t, uv = mod.primary_hits()
+            rids, rt, ruv = ref.primary_hits()
+            same = (ids == rids) & (ids != MISS)
+            assert np.array_equal(t[same], rt[same]) and np.array_equal(uv[same], ruv[same])
+            bad += int((ids != rids).sum())
+            a, b = mod.sample_radiance(3), ref.sample_radiance(3)
+            ok = np.isclose(a[..., :3], b[..., :3], rtol=1e-4, atol=1e-5).all(axis=-1) & (a[..., 3] == b[..., 3])
+            outliers += int((~ok).sum())
+        n = cams * 96 * 54
+        assert bad <= 1e-4 * n
+        assert outliers <= 5e-3 * n
+    finally:
+        mod.Shutdown()
