@@ -16,4 +16,8 @@ for scene in sys.argv[1:] or ["dragon"]:
         print(scene, "pipeline", pipe, f"lane utilisation: inner {u_inner:.3f} leaf {u_leaf:.3f} shade {u_shade:.3f} gen {u_gen:.3f}",
               f"| per ray: inner visits {st['box_tests']/2/st['rays']:.2f} tri {st['tri_tests']/st['rays']:.2f}",
               f"| wave iters per ray*64: inner {d['wave_inner_iters']*64/st['rays']:.2f} leaf {d['wave_leaf_iters']*64/st['rays']:.2f} shade {d['wave_shade_calls']*64/st['rays']:.2f}")
+        if d["cycles_kernel"]:
+            k = d["cycles_kernel"]
+            rest = k - d["cycles_inner"] - d["cycles_leaf"] - d["cycles_shade"] - d["cycles_refill"]
+            print(f"   wave time split: inner {d['cycles_inner']/k:.3f} leaf {d['cycles_leaf']/k:.3f} shade {d['cycles_shade']/k:.3f} refill+generate {d['cycles_refill']/k:.3f} votes/tile bookkeeping {rest/k:.3f}")
         mod.Shutdown()

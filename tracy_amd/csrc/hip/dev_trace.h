@@ -72,6 +72,7 @@ DEVFN uint32_t path_rng_state(uint32_t pixel_index, uint32_t sample_index, uint3
 struct Counters {
     uint32_t rays, box_tests, tri_tests, hits, tex_fetches;
     uint32_t w_inner, w_leaf, w_shade, w_gen, l_gen;   // instrumented kernel only
+    unsigned long long cyc[5];                         // instrumented kernel only: wave cycles per phase (see DevCounters)
 };
 // true for exactly one of the currently active lanes (wave-level event counting)
 DEVFN bool first_active_lane() {

@@ -64,5 +64,7 @@ struct DevCounters {
     unsigned long long rays, samples, box_tests, tri_tests, hits, tex_fetches;
     // wave-level iteration counts (instrumented kernel only): lane utilisation per phase =
     // lane-level count / (64 * wave-level count)
-    unsigned long long wave_inner_iters, wave_leaf_iters, wave_shade_calls, wave_gen_calls, lanes_gen, pad[5];
+    unsigned long long wave_inner_iters, wave_leaf_iters, wave_shade_calls, wave_gen_calls, lanes_gen;
+    // shader-clock cycles the waves spent per phase (instrumented kernel only): inner steps, triangle steps, shade, refill/generate, whole kernel
+    unsigned long long phase_cycles[5];
 };

@@ -60,6 +60,7 @@ DEVFN void flush_counters(const Counters& c, DevCounters* g) {
             atomicAdd(&g->wave_shade_calls, (unsigned long long)d);
             atomicAdd(&g->wave_gen_calls, (unsigned long long)e);
             atomicAdd(&g->lanes_gen, (unsigned long long)f);
+            for (int k = 0; k < 5; ++k) atomicAdd(&g->phase_cycles[k], c.cyc[k]);
         }
     }
 }
@@ -155,6 +156,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
     const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
     const uint32_t total = P * rp.spp_count;   // items per tile
     Counters cnt = {};
+    const unsigned long long t_kernel = STATS ? __builtin_readcyclecounter() : 0ull;
 
     for (;;) {
         uint32_t tile = 0;
@@ -183,6 +185,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
 
         for (;;) {
             // ---- shade the lanes whose ray is finished
+            const unsigned long long t_shade = STATS ? __builtin_readcyclecounter() : 0ull;
             if (has_path && !trav_active(tv)) {
                 const bool cont = shade<STATS>(sc, ps, tv.hit, cnt);
                 if (cont) {
@@ -194,6 +197,8 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                     has_path = false;
                 }
             }
+            const unsigned long long t_refill = STATS ? __builtin_readcyclecounter() : 0ull;
+            if (STATS) cnt.cyc[2] += t_refill - t_shade;
             // ---- refill: idle lanes take the next items of the tile, in lane order
             const bool want = !has_path && !exhausted;
             const unsigned long long wmask = __ballot(want);
@@ -218,6 +223,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                 }
                 next += (uint32_t)__popcll(wmask);
             }
+            if (STATS) cnt.cyc[3] += __builtin_readcyclecounter() - t_refill;
             // ---- traverse until enough lanes are waiting again
             unsigned long long tmask = __ballot(trav_active(tv));
             if (tmask == 0ull) {
@@ -235,12 +241,15 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                 const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
                 const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
                 if ((nI | nL) == 0u || nP - nI - nL >= rp.refill_thresh) break;
+                const unsigned long long t_step = STATS ? __builtin_readcyclecounter() : 0ull;
                 if (nI != 0u && nI * 4u >= nL * rp.sched_beta4) {
 #pragma unroll
                     for (int r = 0; r < TRH_INNER_REPEAT; ++r)
                         if (tv.node >= 0) trav_inner<STATS, N16>(sc, ps.o, tv, stack, cnt);
+                    if (STATS) cnt.cyc[0] += __builtin_readcyclecounter() - t_step;
                 } else {
                     if (tv.node < -1) trav_leaf<STATS>(sc, ps.o, ps.d, tv, stack, cnt);
+                    if (STATS) cnt.cyc[1] += __builtin_readcyclecounter() - t_step;
                 }
             }
         }
@@ -258,6 +267,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (STATS) cnt.cyc[4] += __builtin_readcyclecounter() - t_kernel;
     flush_counters<STATS>(cnt, counters);
 }
 
@@ -1037,8 +1047,9 @@ int trh_get_debug_counters(trh_context* c, uint64_t* out, uint32_t n) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     DevCounters h{};
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
-    const uint64_t v[5] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen};
-    for (uint32_t i = 0; i < n; ++i) out[i] = i < 5 ? v[i] : 0;
+    const uint64_t v[10] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen,
+                            h.phase_cycles[0], h.phase_cycles[1], h.phase_cycles[2], h.phase_cycles[3], h.phase_cycles[4]};
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 10 ? v[i] : 0;
     return TRH_OK;
 }
 

@@ -146,9 +146,10 @@ class HipTrace:
 
     def debug_counters(self):
         """Wave-level iteration counts of the instrumented kernel (see trh_get_debug_counters)."""
-        out = (C.c_uint64 * 5)()
-        self._check(self._lib.trh_get_debug_counters(self._ctx, out, 5))
-        return dict(zip(["wave_inner_iters", "wave_leaf_iters", "wave_shade_calls", "wave_gen_calls", "lanes_gen"], list(out)))
+        out = (C.c_uint64 * 10)()
+        self._check(self._lib.trh_get_debug_counters(self._ctx, out, 10))
+        return dict(zip(["wave_inner_iters", "wave_leaf_iters", "wave_shade_calls", "wave_gen_calls", "lanes_gen",
+                         "cycles_inner", "cycles_leaf", "cycles_shade", "cycles_refill", "cycles_kernel"], list(out)))
 
     def bvh_info(self):
         b = capi.trh_bvh_info()
