@@ -142,6 +142,24 @@ int trh_reset_accumulation(trh_context* ctx);
 
 int trh_set_pipeline(trh_context* ctx, int pipeline /* trh_pipeline */);
 
+/* Debug views: the run-time form of the reference's compile-time DEBUG_SHOW_* switches
+ * (CMakeLists.txt:23-35; cpu_trace.cpp:127-137, cuda_trace.cu:94-103). With a view selected every
+ * camera path ends at its first hit and returns one material input instead of radiance: base colour,
+ * .5 * normalize(1 + mat3(view) * normal), metalness, roughness or emissive (textures included); a
+ * path that misses returns the sky as usual. view3x3 = the upper-left 3x3 of Camera::GetView
+ * (src/camera.h:57), column-major, 9 floats, used by the NORMALS view only; NULL keeps the last one
+ * (identity at start). Takes effect for the next trh_render / trh_sample_radiance; does not reset the
+ * accumulation. */
+typedef enum trh_debug_view {
+    TRH_VIEW_NONE = 0,
+    TRH_VIEW_BASECOLOR = 1,
+    TRH_VIEW_NORMALS = 2,
+    TRH_VIEW_METALNESS = 3,
+    TRH_VIEW_ROUGHNESS = 4,
+    TRH_VIEW_EMISSIVE = 5
+} trh_debug_view;
+int trh_set_debug_view(trh_context* ctx, int view /* trh_debug_view */, const float view3x3[9]);
+
 /* THE HOT CALL. Replaces CpuTrace::OnUpdate + Trace (cpu_trace.cpp:33-170): traces
  * samples [spp_begin, spp_begin+spp_count) of every pixel (one camera path each) and adds
  * their radiance into the context's float4 accumulation buffer (rgb sum, .w = count).

@@ -394,6 +394,10 @@ struct oref_scene {
     u32 width = 0, height = 0, max_bounces = 5, flags = TRH_FLAG_DEFAULT;
     vec3 eye;
     float ivp[16]{};
+    // run-time form of the DEBUG_SHOW_* compile-time switches (CMakeLists.txt:23-35): 0 none, 1 base colour,
+    // 2 normals, 3 metalness, 4 roughness, 5 emissive; view3 = mat3(Camera::GetView()), column-major
+    u32 debug_view = 0;
+    float view3[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     // accel (cpu_details.h:101-107)
     FlatTree<Obj> TLAS_tree;
     std::vector<FlatTree<Tri>> BLAS_tree;
@@ -598,6 +602,22 @@ vec3 Trace(const oref_scene& s, Ray ray, u32& rng, u64& raycount, TraversalCount
         hit.t = FLT_MAX;
         vec3 attenuation, emission;
         if (ComputeIntersection(s, current_ray, hit, cnt)) {
+            if (s.debug_view) {   // cpu_trace.cpp:127-137: the path ends at its first hit and returns one material input
+                const trh_material& m = s.materials[hit.material];
+                if (bounces_out) *bounces_out = iters;
+                switch (s.debug_view) {
+                case 1: return GetBaseColor(s, m, hit);
+                case 2: {   // .5f * normalize((1.f + mat3(view) * normal))
+                    const vec3 n = GetNormal(s, m, hit);
+                    const float* v = s.view3;   // glm mat3 * vec3: (col0 * x + col1 * y) + col2 * z
+                    const vec3 vn{(v[0] * n.x + v[3] * n.y) + v[6] * n.z, (v[1] * n.x + v[4] * n.y) + v[7] * n.z, (v[2] * n.x + v[5] * n.y) + v[8] * n.z};
+                    return 0.5f * normalize(vec3{1.f + vn.x, 1.f + vn.y, 1.f + vn.z});
+                }
+                case 3: { const float x = GetMetalness(s, m, hit); return vec3{x, x, x}; }
+                case 4: { const float x = GetRoughness(s, m, hit); return vec3{x, x, x}; }
+                default: return GetEmissive(s, m, hit);
+                }
+            }
             Ray next;
             Scatter(s, s.materials[hit.material], current_ray, hit, attenuation, emission, next, rng);
             current_ray = next;
@@ -655,6 +675,11 @@ void oref_destroy(oref_scene* s) { delete s; }
 void oref_set_camera(oref_scene* s, const float eye[3], const float inv_view_proj[16]) {
     s->eye = vec3(eye[0], eye[1], eye[2]);
     memcpy(s->ivp, inv_view_proj, sizeof(s->ivp));
+}
+
+void oref_set_debug_view(oref_scene* s, int view, const float view3x3[9]) {
+    s->debug_view = (u32)view;
+    if (view3x3) memcpy(s->view3, view3x3, sizeof(s->view3));
 }
 
 // TracyEvent::eCameraCut (cpu_trace.cpp:76-78). The reference keeps output[] and only resets the

@@ -23,6 +23,7 @@ def lib():
         L.oref_destroy.argtypes = [C.c_void_p]
         L.oref_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oref_reset.argtypes = [C.c_void_p]
+        L.oref_set_debug_view.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oref_tree_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.oref_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oref_sample_radiance.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
@@ -68,6 +69,10 @@ class CpuRef:
         eye = np.ascontiguousarray(eye, dtype=np.float32)
         ivp = np.ascontiguousarray(ivp, dtype=np.float32)
         self.L.oref_set_camera(self._h, eye.ctypes.data, ivp.ctypes.data)
+
+    def set_debug_view(self, view, view3x3=None):
+        v = None if view3x3 is None else np.ascontiguousarray(view3x3, dtype=np.float32).reshape(9)
+        self.L.oref_set_debug_view(self._h, int(view), None if v is None else v.ctypes.data)
 
     def reset(self):
         self.L.oref_reset(self._h)

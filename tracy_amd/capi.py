@@ -18,6 +18,7 @@ TRH_PIPELINE_MEGAKERNEL = 0
 TRH_PIPELINE_WAVEFRONT = 1
 TRH_PIPELINE_MEGAKERNEL_SIMPLE = 2
 TRH_TONEMAP_NONE, TRH_TONEMAP_SRGB, TRH_TONEMAP_REINHARD, TRH_TONEMAP_ACES = 0, 1, 2, 3
+TRH_VIEW_NONE, TRH_VIEW_BASECOLOR, TRH_VIEW_NORMALS, TRH_VIEW_METALNESS, TRH_VIEW_ROUGHNESS, TRH_VIEW_EMISSIVE = 0, 1, 2, 3, 4, 5
 
 
 class trh_material(C.Structure):
@@ -96,6 +97,7 @@ HIP_SYMBOLS = {
     "trh_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "trh_reset_accumulation": (C.c_int, [C.c_void_p]),
     "trh_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+    "trh_set_debug_view": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "trh_render": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "trh_render_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "trh_synchronize": (C.c_int, [C.c_void_p]),

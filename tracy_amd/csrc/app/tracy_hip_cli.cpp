@@ -5,7 +5,8 @@
 // server. Extra flags: -width/-height (override OUT), -spp N (stop after N samples per pixel),
 // -spu K (samples per OnUpdate), -out file.pfm (linear) | file.ppm | file.png (tonemapped picture),
 // -tonemap srgb|reinhard|aces|none and -exposure E (the reference's TRACY_TONEMAPPING / TRACY_EXPOSURE
-// build options, CMakeLists.txt:92-103), -device D.
+// build options, CMakeLists.txt:92-103), -debug basecolor|normals|metalness|roughness|emissive (the DEBUG_SHOW_*
+// build options, CMakeLists.txt:23-35), -device D.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -101,7 +102,7 @@ int main(int argc, char** argv) {
     uint32_t WIDTH = 640, HEIGHT = 480;   // win_raytracer.cpp:439-440
     std::string scene_path = "data/default.scn", kernelname = "hip", out_path, asset_root = ".";
     uint32_t spp = 64, spu = 1;
-    int device = 0, tonemap = TRH_TONEMAP_SRGB;
+    int device = 0, tonemap = TRH_TONEMAP_SRGB, debug_view = TRH_VIEW_NONE;
     float exposure = 1.f;
     bool override_size = false;
     for (int i = 1; i < argc; ++i) {
@@ -117,6 +118,11 @@ int main(int argc, char** argv) {
         else if (a == "-assets") asset_root = next(".");
         else if (a == "-device") device = atoi(next("0"));
         else if (a == "-exposure") exposure = (float)atof(next("1"));
+        else if (a == "-debug") {   // the reference's DEBUG_SHOW_* build options (CMakeLists.txt:23-35)
+            const std::string t = next("none");
+            debug_view = t == "basecolor" ? TRH_VIEW_BASECOLOR : t == "normals" ? TRH_VIEW_NORMALS : t == "metalness" ? TRH_VIEW_METALNESS
+                       : t == "roughness" ? TRH_VIEW_ROUGHNESS : t == "emissive" ? TRH_VIEW_EMISSIVE : TRH_VIEW_NONE;
+        }
         else if (a == "-tonemap") {
             const std::string t = next("srgb");
             tonemap = t == "none" ? TRH_TONEMAP_NONE : t == "reinhard" ? TRH_TONEMAP_REINHARD : t == "aces" ? TRH_TONEMAP_ACES : TRH_TONEMAP_SRGB;
@@ -136,6 +142,7 @@ int main(int argc, char** argv) {
     handle_t win{WIDTH, HEIGHT};
     HipTrace kernel(device, spu);
     kernel.SetTonemap(tonemap, exposure);
+    kernel.SetDebugView(debug_view);
     if (!kernel.Startup(&win, world)) {
         fprintf(stderr, "Kernel failed to initialize\n");   // win_raytracer.cpp:572-575
         return EXIT_FAILURE;

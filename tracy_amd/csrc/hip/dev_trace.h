@@ -371,6 +371,21 @@ DEVFN bool shade(const DevScene& sc, PathState& ps, const Hit& hit, Counters& cn
             normal = normalize(bitangent * nm.x + tangent * nm.y + normal * nm.z);
         }
 
+        // ---- debug views (cpu_trace.cpp:127-137): the path ends here and returns one material input
+        if (sc.debug_view != 0u) {
+            V3 out = emissive;
+            if (sc.debug_view == 1u) out = basecolor;
+            else if (sc.debug_view == 2u) {
+                const float* v = sc.view3;   // glm mat3 * vec3: (col0 * x + col1 * y) + col2 * z
+                const V3 vn = mk((v[0] * normal.x + v[3] * normal.y) + v[6] * normal.z, (v[1] * normal.x + v[4] * normal.y) + v[7] * normal.z,
+                                 (v[2] * normal.x + v[5] * normal.y) + v[8] * normal.z);
+                out = 0.5f * normalize(mk(1.f + vn.x, 1.f + vn.y, 1.f + vn.z));
+            } else if (sc.debug_view == 3u) out = mk(metalness, metalness, metalness);
+            else if (sc.debug_view == 4u) out = mk(roughness, roughness, roughness);
+            ps.radiance = out;
+            return false;
+        }
+
         // ---- Material::Scatter (src/material.h:210-268)
         const V3 raydir = ps.d;
         const float VdotN = dot(raydir, normal);

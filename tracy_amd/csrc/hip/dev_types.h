@@ -46,6 +46,8 @@ struct DevScene {
     float frame_c[3];          // BVH frame: x' = (x - frame_c) * frame_s, frame_s a power of two
     float frame_sinv;          // 1 / frame_s
     float frame_inv_lim;       // largest |1/d| whose product with frame_sinv stays finite
+    uint32_t debug_view;       // trh_debug_view (0 = render radiance)
+    float view3[9];            // mat3(Camera::GetView()), column-major: the NORMALS debug view
 };
 
 struct RenderParams {

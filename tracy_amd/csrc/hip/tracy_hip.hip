@@ -379,6 +379,8 @@ uint32_t seed_hash_of(uint64_t seed) {
 }  // namespace
 
 struct trh_context {
+    uint32_t debug_view = 0;
+    float view3[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
@@ -834,6 +836,8 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     // keep the camera if one was set before (re-upload of a scene)
     memcpy(sc.eye, c->sc.eye, sizeof(sc.eye));
     memcpy(sc.ivp, c->sc.ivp, sizeof(sc.ivp));
+    sc.debug_view = c->debug_view;
+    memcpy(sc.view3, c->view3, sizeof(sc.view3));
 
     const size_t npix = (size_t)d->width * d->height;
     void* p = nullptr;
@@ -907,6 +911,16 @@ int trh_reset_accumulation(trh_context* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)c->sc.width * c->sc.height * sizeof(float4), c->stream));
     c->accum_spp = 0;
+    return TRH_OK;
+}
+
+int trh_set_debug_view(trh_context* c, int view, const float view3x3[9]) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_set_debug_view: ctx is NULL");
+    if (view < TRH_VIEW_NONE || view > TRH_VIEW_EMISSIVE) return fail(TRH_ERR_INVALID_ARG, "trh_set_debug_view: unknown view");
+    c->debug_view = (uint32_t)view;
+    if (view3x3) memcpy(c->view3, view3x3, sizeof(c->view3));
+    c->sc.debug_view = c->debug_view;
+    memcpy(c->sc.view3, c->view3, sizeof(c->view3));
     return TRH_OK;
 }
 

@@ -33,6 +33,7 @@ struct FlatScene {
     trh_scene_desc desc{};
     float eye[3]{};
     float inv_view_proj[16]{};
+    float view3[9]{};   // mat3(Camera::GetView()), column-major
 };
 
 // 4x4 column-major helpers (Camera keeps inverse(projection * view) private, camera.h:84)
@@ -135,7 +136,10 @@ bool FlattenCamera(const SceneT& scene, FlatScene& out) {
     const auto& e = cam.GetPosition();
     out.eye[0] = e.x; out.eye[1] = e.y; out.eye[2] = e.z;
     float pv[16];
-    Mul4x4(reinterpret_cast<const float*>(&cam.GetProjection()), reinterpret_cast<const float*>(&cam.GetView()), pv);
+    const float* view = reinterpret_cast<const float*>(&cam.GetView());
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) out.view3[c * 3 + r] = view[c * 4 + r];
+    Mul4x4(reinterpret_cast<const float*>(&cam.GetProjection()), view, pv);
     return Invert4x4(pv, out.inv_view_proj);
 }
 
@@ -152,6 +156,7 @@ public:
         if (!FlattenScene(in_Scene, flat)) return Fail("FlattenScene");
         if (trh_scene_upload(ctx_, &flat.desc) != TRH_OK) return Fail("trh_scene_upload");
         if (trh_set_camera(ctx_, flat.eye, flat.inv_view_proj) != TRH_OK) return Fail("trh_set_camera");
+        if (trh_set_debug_view(ctx_, debug_view_, flat.view3) != TRH_OK) return Fail("trh_set_debug_view");
         width_ = flat.desc.width;
         height_ = flat.desc.height;
         image_.assign(static_cast<size_t>(width_) * height_ * 4, 0.f);
@@ -169,7 +174,10 @@ public:
         (void)in_DeltaTime;
         if (camera_dirty_) {   // pattern of CUDADetails::Update (cuda_details.cpp:206-215)
             FlatScene cam;
-            if (FlattenCamera(in_Scene, cam)) Check(trh_set_camera(ctx_, cam.eye, cam.inv_view_proj), "trh_set_camera");
+            if (FlattenCamera(in_Scene, cam)) {
+                Check(trh_set_camera(ctx_, cam.eye, cam.inv_view_proj), "trh_set_camera");
+                Check(trh_set_debug_view(ctx_, debug_view_, cam.view3), "trh_set_debug_view");
+            }
             Check(trh_reset_accumulation(ctx_), "trh_reset_accumulation");
             next_sample_ = 0;
             camera_dirty_ = false;
@@ -218,6 +226,8 @@ public:
     const uint32_t* GetBitmap() const { return bitmap_.data(); }
     // the reference fixes these at compile time (TRACY_TONEMAPPING / TRACY_EXPOSURE, CMakeLists.txt:92-103)
     void SetTonemap(int in_Tonemap, float in_Exposure) { tonemap_ = in_Tonemap; exposure_ = in_Exposure; }
+    // the reference's DEBUG_SHOW_* build switches (CMakeLists.txt:23-35) at run time; call before Startup or send eCameraCut
+    void SetDebugView(int in_View) { debug_view_ = in_View; camera_dirty_ = ctx_ != nullptr; }
     uint32_t GetWidth() const { return width_; }
     uint32_t GetHeight() const { return height_; }
     uint32_t GetSampleCount() const { return next_sample_; }
@@ -248,6 +258,7 @@ private:
     std::vector<uint32_t> bitmap_;
     int tonemap_ = TRH_TONEMAP_SRGB;   // default build: USE_TONEMAP_SRGB, TRACY_EXPOSURE 1
     float exposure_ = 1.f;
+    int debug_view_ = TRH_VIEW_NONE;
 };
 
 }  // namespace tracy_hip

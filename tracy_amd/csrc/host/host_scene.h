@@ -50,6 +50,8 @@ inline bool FlattenCamera(const HostScene& scene, FlatScene& out) {
     if (!scene.GetCamera(c)) return false;
     memcpy(out.eye, c.eye, sizeof(out.eye));
     memcpy(out.inv_view_proj, c.inv_view_proj, sizeof(out.inv_view_proj));
+    for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row) out.view3[col * 3 + row] = c.view[col * 4 + row];
     return true;
 }
 inline bool FlattenScene(const HostScene& scene, FlatScene& out) {

@@ -89,6 +89,11 @@ class HipTrace:
         ivp = np.ascontiguousarray(ivp, dtype=np.float32)
         self._check(self._lib.trh_set_camera(self._ctx, eye.ctypes.data_as(C.POINTER(C.c_float)), ivp.ctypes.data_as(C.POINTER(C.c_float))))
 
+    def set_debug_view(self, view, view3x3=None):
+        """trh_set_debug_view: the reference's DEBUG_SHOW_* switches at run time (cpu_trace.cpp:127-137)."""
+        v = None if view3x3 is None else np.ascontiguousarray(view3x3, dtype=np.float32).reshape(9)
+        self._check(self._lib.trh_set_debug_view(self._ctx, int(view), None if v is None else v.ctypes.data))
+
     def set_pipeline(self, pipeline):
         self._check(self._lib.trh_set_pipeline(self._ctx, int(pipeline)))
 

@@ -100,6 +100,11 @@ class Scene:
         cam = self.camera()
         return (np.array(cam.eye[:], dtype=np.float32), np.array(cam.inv_view_proj[:], dtype=np.float32))
 
+    def view3x3(self):
+        """mat3(Camera::GetView()), column-major, 9 floats (the NORMALS debug view needs it)."""
+        v = np.array(self.camera().view[:], dtype=np.float32).reshape(4, 4)   # row i = column i
+        return np.ascontiguousarray(v[:3, :3]).reshape(9)
+
     def set_view(self, eye, center, up):
         f3 = C.c_float * 3
         rc = self._lib.tsc_set_view(self._h, f3(*eye), f3(*center), f3(*up))
