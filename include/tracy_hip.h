@@ -132,6 +132,17 @@ int trh_shutdown(trh_context* ctx);
  * host, lays nodes/triangles out in 64 B-aligned arrays and copies them to HBM. */
 int trh_scene_upload(trh_context* ctx, const trh_scene_desc* scene);
 
+/* Which builder trh_scene_upload uses for the acceleration structure (call before the upload):
+ * the host-side binned-SAH build (default: best traversal speed, tens of ms per 100k triangles on the
+ * host cores) or the device-side linear BVH (Morton sort + Karras hierarchy on the GPU: milliseconds
+ * for millions of triangles, but 25-40 % slower to traverse). Both emit the same record formats and leaf
+ * links, so every kernel runs unchanged. Scenes of < 9 triangles, and trees the linear build makes
+ * deeper than the traversal stack (32), are built by the host builder whatever the setting;
+ * trh_bvh_info.builder tells which one built the resident structure. No counterpart in the
+ * reference (its kd-tree is always built on the host, kdtree.h:160-354). */
+typedef enum trh_builder { TRH_BUILDER_HOST_SAH = 0, TRH_BUILDER_DEVICE_LBVH = 1 } trh_builder;
+int trh_set_builder(trh_context* ctx, int builder /* trh_builder */);
+
 /* Camera (re)upload. Replaces CUDATraceKernel::UpdateCamera (cuda_trace.cu:221-225).
  * inv_view_proj is column-major, = inverse(projection * view) (src/camera.h:45,54).
  * Does NOT reset the accumulation (call trh_reset_accumulation for a camera cut). */
@@ -238,6 +249,9 @@ typedef struct trh_bvh_info {
     double   sah_cost;
     double   build_ms;
     double   fp16_inflation;  /* box-area growth of the 32-byte fp16 records; node_bytes / node_count tells which format is in use */
+    uint32_t builder;         /* trh_builder that produced it */
+    uint32_t reserved;
+    double   device_build_ms; /* device LBVH only: HIP-event time of its kernels + sort (build_ms is the wall time incl. the upload) */
 } trh_bvh_info;
 int trh_get_bvh_info(trh_context* ctx, trh_bvh_info* out);
 
@@ -249,6 +263,11 @@ int trh_get_bvh_info(trh_context* ctx, trh_bvh_info* out);
  * number of builder threads (TRH_BUILD_THREADS). No counterpart in the reference (its kd-tree build,
  * kdtree.h:160-354, is not what the kernels traverse). */
 int trh_bvh_build_host(const trh_scene_desc* scene, trh_bvh_info* info_out, uint64_t* hash_out, uint64_t* violations_out);
+
+/* The same check for the device-side builder: builds the linear BVH of the scene on ctx's device, copies
+ * the arrays back and runs the same structural self-check and hash on them. Leaves the context's resident
+ * scene alone. Fails with TRH_ERR_LIMIT where trh_scene_upload would fall back to the host builder. */
+int trh_bvh_build_device(trh_context* ctx, const trh_scene_desc* scene, trh_bvh_info* info_out, uint64_t* hash_out, uint64_t* violations_out);
 
 #ifdef __cplusplus
 }

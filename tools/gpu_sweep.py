@@ -14,7 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         t0 = time.time(); mod.render(1000 + i * spp, spp); mod.synchronize(); best = min(best, time.time() - t0)
     st = mod.stats(reset=True)
     print(json.dumps({"ms": best * 1e3, "msamples": w * h * spp / best / 1e6, "mrays": st["rays"] / 3 / best / 1e6,
-                      "tris": bi["tri_count"], "nodes": bi["node_count"], "depth": bi["max_depth"], "build_ms": round(bi["build_ms"], 1),
+                      "tris": bi["tri_count"], "nodes": bi["node_count"], "depth": bi["max_depth"], "build_ms": round(bi["build_ms"], 1), "builder": bi["builder"], "device_build_ms": round(bi["device_build_ms"], 2), "sah": round(bi["sah_cost"], 1),
                       "n_box": round(st0["box_tests"] / st0["rays"], 2), "n_tri": round(st0["tri_tests"] / st0["rays"], 2)}))
     sys.exit(0)
 configs = []

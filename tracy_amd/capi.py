@@ -18,6 +18,7 @@ TRH_PIPELINE_MEGAKERNEL = 0
 TRH_PIPELINE_WAVEFRONT = 1
 TRH_PIPELINE_MEGAKERNEL_SIMPLE = 2
 TRH_TONEMAP_NONE, TRH_TONEMAP_SRGB, TRH_TONEMAP_REINHARD, TRH_TONEMAP_ACES = 0, 1, 2, 3
+TRH_BUILDER_HOST_SAH, TRH_BUILDER_DEVICE_LBVH = 0, 1
 TRH_VIEW_NONE, TRH_VIEW_BASECOLOR, TRH_VIEW_NORMALS, TRH_VIEW_METALNESS, TRH_VIEW_ROUGHNESS, TRH_VIEW_EMISSIVE = 0, 1, 2, 3, 4, 5
 
 
@@ -52,7 +53,7 @@ class trh_stats(C.Structure):
 class trh_bvh_info(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("tri_count", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
                 ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("sah_cost", C.c_double), ("build_ms", C.c_double),
-                ("fp16_inflation", C.c_double)]
+                ("fp16_inflation", C.c_double), ("builder", C.c_uint32), ("reserved", C.c_uint32), ("device_build_ms", C.c_double)]
 
 
 class tsc_camera(C.Structure):
@@ -110,6 +111,8 @@ HIP_SYMBOLS = {
     "trh_get_stats": (C.c_int, [C.c_void_p, C.POINTER(trh_stats), C.c_int]),
     "trh_get_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32]),
     "trh_bvh_build_host": (C.c_int, [C.POINTER(trh_scene_desc), C.POINTER(trh_bvh_info), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "trh_bvh_build_device": (C.c_int, [C.c_void_p, C.POINTER(trh_scene_desc), C.POINTER(trh_bvh_info), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "trh_set_builder": (C.c_int, [C.c_void_p, C.c_int]),
     "trh_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(trh_bvh_info)]),
 }
 

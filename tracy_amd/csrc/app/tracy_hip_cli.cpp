@@ -6,7 +6,7 @@
 // -spu K (samples per OnUpdate), -out file.pfm (linear) | file.ppm | file.png (tonemapped picture),
 // -tonemap srgb|reinhard|aces|none and -exposure E (the reference's TRACY_TONEMAPPING / TRACY_EXPOSURE
 // build options, CMakeLists.txt:92-103), -debug basecolor|normals|metalness|roughness|emissive (the DEBUG_SHOW_*
-// build options, CMakeLists.txt:23-35), -device D.
+// build options, CMakeLists.txt:23-35), -builder sah|lbvh (host binned-SAH build, or the device-side linear BVH), -device D.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
     uint32_t WIDTH = 640, HEIGHT = 480;   // win_raytracer.cpp:439-440
     std::string scene_path = "data/default.scn", kernelname = "hip", out_path, asset_root = ".";
     uint32_t spp = 64, spu = 1;
-    int device = 0, tonemap = TRH_TONEMAP_SRGB, debug_view = TRH_VIEW_NONE;
+    int device = 0, tonemap = TRH_TONEMAP_SRGB, debug_view = TRH_VIEW_NONE, builder = TRH_BUILDER_HOST_SAH;
     float exposure = 1.f;
     bool override_size = false;
     for (int i = 1; i < argc; ++i) {
@@ -123,6 +123,7 @@ int main(int argc, char** argv) {
             debug_view = t == "basecolor" ? TRH_VIEW_BASECOLOR : t == "normals" ? TRH_VIEW_NORMALS : t == "metalness" ? TRH_VIEW_METALNESS
                        : t == "roughness" ? TRH_VIEW_ROUGHNESS : t == "emissive" ? TRH_VIEW_EMISSIVE : TRH_VIEW_NONE;
         }
+        else if (a == "-builder") builder = std::string(next("sah")) == "lbvh" ? TRH_BUILDER_DEVICE_LBVH : TRH_BUILDER_HOST_SAH;
         else if (a == "-tonemap") {
             const std::string t = next("srgb");
             tonemap = t == "none" ? TRH_TONEMAP_NONE : t == "reinhard" ? TRH_TONEMAP_REINHARD : t == "aces" ? TRH_TONEMAP_ACES : TRH_TONEMAP_SRGB;
@@ -143,6 +144,7 @@ int main(int argc, char** argv) {
     HipTrace kernel(device, spu);
     kernel.SetTonemap(tonemap, exposure);
     kernel.SetDebugView(debug_view);
+    kernel.SetBuilder(builder);
     if (!kernel.Startup(&win, world)) {
         fprintf(stderr, "Kernel failed to initialize\n");   // win_raytracer.cpp:572-575
         return EXIT_FAILURE;

@@ -16,6 +16,7 @@
 // ds_read/ds_write_b32 are bank-conflict free at any depth; the megakernel sizes them to the tree's depth.
 #include "../../../include/tracy_hip.h"
 #include "../host/bvh_builder.h"
+#include "lbvh_build.h"
 #include "dev_trace.h"
 
 #include <algorithm>
@@ -379,6 +380,7 @@ uint32_t seed_hash_of(uint64_t seed) {
 }  // namespace
 
 struct trh_context {
+    int builder = TRH_BUILDER_HOST_SAH;
     uint32_t debug_view = 0;
     float view3[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     int device = 0;
@@ -701,6 +703,7 @@ int trh_init(int device, trh_context** ctx_out) {
         if (v >= 8 && v <= 26) c->wf_pool_limit = 1u << v;
     }
     if (const char* e = getenv("TRH_LDS_PAD")) c->lds_pad = (size_t)atoi(e);
+    if (const char* e = getenv("TRH_BUILDER")) c->builder = strcmp(e, "lbvh") == 0 ? TRH_BUILDER_DEVICE_LBVH : TRH_BUILDER_HOST_SAH;   // default builder of this context
     if (const char* e = getenv("TRH_SCHED_BETA4")) {     // development knob
         const int v = atoi(e);
         if (v >= 0 && v <= 256) c->sched_beta4 = (uint32_t)v;
@@ -736,10 +739,38 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     bool any_normal_map = false;
     if (int frc = flatten_triangles(d, tris, any_normal_map)) return frc;
 
-    // ---- build the BVH on the host
+    // ---- build the BVH: on the host (binned SAH, default) or on the device (linear BVH)
     const auto t0 = std::chrono::steady_clock::now();
     bvh::Result r;
-    bvh::build(tris, r);
+    lbvh::DeviceBvh dev_bvh;
+    bool built_on_device = false;
+    if (c->builder == TRH_BUILDER_DEVICE_LBVH && tris.size() >= lbvh::kMinTriangles) {
+        std::string why;
+        const int brc = lbvh::build(tris, c->stream, dev_bvh, why);
+        if (brc == 0) {
+            built_on_device = true;
+            // the arrays stay in HBM; the host needs the leaf order (shading records) and the scalars
+            r.prim_index.resize(tris.size());
+            HIP_TRY(hipMemcpyAsync(r.prim_index.data(), dev_bvh.prim_index, tris.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(dev_bvh.prim_index);
+            dev_bvh.prim_index = nullptr;
+            c->allocs.push_back(dev_bvh.nodes);
+            c->allocs.push_back(dev_bvh.nodes16);
+            c->allocs.push_back(dev_bvh.tris);
+            memcpy(r.frame_center, dev_bvh.frame_center, sizeof(r.frame_center));
+            r.frame_scale = dev_bvh.frame_scale;
+            r.fp16_inflation = dev_bvh.fp16_inflation;
+            r.max_depth = dev_bvh.max_depth;
+            r.max_leaf = dev_bvh.max_leaf;
+            r.sah_cost = dev_bvh.sah_cost;
+        } else if (brc != 2) {   // 2 = deeper than the traversal stack: the host builder bounds its depth
+            return fail(TRH_ERR_HIP, why.c_str());
+        } else if (getenv("TRH_VERBOSE")) {
+            fprintf(stderr, "trh_scene_upload: %s; using the host builder\n", why.c_str());
+        }
+    }
+    if (!built_on_device) bvh::build(tris, r);
     const auto t1 = std::chrono::steady_clock::now();
     if (r.max_depth > (uint32_t)TRH_STACK_SIZE) return fail(TRH_ERR_LIMIT, "trh_scene_upload: BVH deeper than the traversal stack");
 
@@ -773,22 +804,40 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
         if (atoi(e) == 16) use_fp16 = true;
         if (atoi(e) == 32) use_fp16 = false;
     }
+    auto drop = [c](void* p) {   // the record format that is not used
+        c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), p), c->allocs.end());
+        (void)hipFree(p);
+    };
     if (use_fp16) {
-        uint32_t* dq = nullptr;
-        if ((rc = dev_alloc_copy(c, r.nodes16.data(), r.nodes16.size(), &dq))) return rc;
-        sc.nodes16 = (const uint4*)dq;
+        if (built_on_device) {
+            sc.nodes16 = (const uint4*)dev_bvh.nodes16;
+            drop(dev_bvh.nodes);
+        } else {
+            uint32_t* dq = nullptr;
+            if ((rc = dev_alloc_copy(c, r.nodes16.data(), r.nodes16.size(), &dq))) return rc;
+            sc.nodes16 = (const uint4*)dq;
+        }
         memcpy(sc.frame_c, r.frame_center, 12);
         sc.frame_sinv = 1.f / r.frame_scale;
         sc.frame_inv_lim = r.frame_scale < 1.f ? 3.0e38f * r.frame_scale : 3.402823466e+38f;
     } else {
-        if ((rc = dev_alloc_copy(c, r.nodes.data(), r.nodes.size(), &dp))) return rc;
-        sc.nodes = (const float4*)dp;
+        if (built_on_device) {
+            sc.nodes = (const float4*)dev_bvh.nodes;
+            drop(dev_bvh.nodes16);
+        } else {
+            if ((rc = dev_alloc_copy(c, r.nodes.data(), r.nodes.size(), &dp))) return rc;
+            sc.nodes = (const float4*)dp;
+        }
         sc.frame_c[0] = sc.frame_c[1] = sc.frame_c[2] = 0.f;
         sc.frame_sinv = 1.f;
         sc.frame_inv_lim = 3.402823466e+38f;
     }
-    if ((rc = dev_alloc_copy(c, r.tris.data(), r.tris.size(), &dp))) return rc;
-    sc.tris = (const float4*)dp;
+    if (built_on_device) {
+        sc.tris = (const float4*)dev_bvh.tris;
+    } else {
+        if ((rc = dev_alloc_copy(c, r.tris.data(), r.tris.size(), &dp))) return rc;
+        sc.tris = (const float4*)dp;
+    }
     if ((rc = dev_alloc_copy(c, shade.data(), shade.size(), &dp))) return rc;
     sc.shade = (const float4*)dp;
     if (any_normal_map) {
@@ -858,13 +907,16 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     c->has_scene = true;
     c->samples = 0;
     c->accum_spp = 0;
-    c->bvh.node_count = (uint32_t)(r.nodes.size() / 16);
+    c->bvh.node_count = built_on_device ? dev_bvh.node_count : (uint32_t)(r.nodes.size() / 16);
     c->bvh.tri_count = (uint32_t)nprim;
     c->bvh.max_depth = r.max_depth;
     c->bvh.max_leaf_size = r.max_leaf;
-    c->bvh.node_bytes = use_fp16 ? r.nodes16.size() * 4 : r.nodes.size() * 4;   // the records the kernels traverse
+    c->bvh.node_bytes = (uint64_t)c->bvh.node_count * (use_fp16 ? 32u : 64u);   // the records the kernels traverse
     c->bvh.fp16_inflation = r.fp16_inflation;
-    c->bvh.tri_bytes = r.tris.size() * 4;
+    c->bvh.tri_bytes = (uint64_t)nprim * 48u;
+    c->bvh.builder = built_on_device ? TRH_BUILDER_DEVICE_LBVH : TRH_BUILDER_HOST_SAH;
+    c->bvh.reserved = 0;
+    c->bvh.device_build_ms = built_on_device ? dev_bvh.device_ms : 0.0;
     c->bvh.sah_cost = r.sah_cost;
     c->bvh.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     return TRH_OK;
@@ -893,7 +945,55 @@ int trh_bvh_build_host(const trh_scene_desc* d, trh_bvh_info* info_out, uint64_t
         info_out->sah_cost = r.sah_cost;
         info_out->build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         info_out->fp16_inflation = r.fp16_inflation;
+        info_out->builder = TRH_BUILDER_HOST_SAH;
+        info_out->reserved = 0;
+        info_out->device_build_ms = 0.0;
     }
+    return TRH_OK;
+}
+
+int trh_bvh_build_device(trh_context* c, const trh_scene_desc* d, trh_bvh_info* info_out, uint64_t* hash_out, uint64_t* violations_out) {
+    if (!c || !d || !violations_out) return fail(TRH_ERR_INVALID_ARG, "trh_bvh_build_device: NULL argument");
+    std::vector<bvh::InputTriangle> tris;
+    bool any_normal_map = false;
+    if (int frc = flatten_triangles(d, tris, any_normal_map)) return frc;
+    if (tris.size() < lbvh::kMinTriangles) return fail(TRH_ERR_LIMIT, "trh_bvh_build_device: fewer than 9 triangles (the host builder handles these)");
+    HIP_TRY(hipSetDevice(c->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    lbvh::DeviceBvh dev_bvh;
+    std::string why;
+    const int brc = lbvh::build(tris, c->stream, dev_bvh, why);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (brc != 0) return fail(brc == 2 ? TRH_ERR_LIMIT : TRH_ERR_HIP, why.c_str());
+    bvh::Result r;
+    const int drc = lbvh::download(dev_bvh, c->stream, r, why);
+    const double device_ms = dev_bvh.device_ms;
+    lbvh::release(dev_bvh);
+    if (drc != 0) return fail(TRH_ERR_HIP, why.c_str());
+    *violations_out = bvh::validate(tris, r, why, hash_out);
+    if (*violations_out) g_err = "trh_bvh_build_device: " + why;
+    if (info_out) {
+        const bool use_fp16 = r.fp16_inflation <= bvh::kMaxFp16Inflation;
+        info_out->node_count = (uint32_t)(r.nodes.size() / 16);
+        info_out->tri_count = (uint32_t)r.prim_index.size();
+        info_out->max_depth = r.max_depth;
+        info_out->max_leaf_size = r.max_leaf;
+        info_out->node_bytes = use_fp16 ? r.nodes16.size() * 4 : r.nodes.size() * 4;
+        info_out->tri_bytes = r.tris.size() * 4;
+        info_out->sah_cost = r.sah_cost;
+        info_out->build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        info_out->fp16_inflation = r.fp16_inflation;
+        info_out->builder = TRH_BUILDER_DEVICE_LBVH;
+        info_out->reserved = 0;
+        info_out->device_build_ms = device_ms;
+    }
+    return TRH_OK;
+}
+
+int trh_set_builder(trh_context* c, int builder) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_set_builder: ctx is NULL");
+    if (builder != TRH_BUILDER_HOST_SAH && builder != TRH_BUILDER_DEVICE_LBVH) return fail(TRH_ERR_INVALID_ARG, "trh_set_builder: unknown builder");
+    c->builder = builder;
     return TRH_OK;
 }
 

@@ -1,5 +1,6 @@
 // bvh_builder.cpp -- binned-SAH BVH2 build, see bvh_builder.h for the layout.
 #include "bvh_builder.h"
+#include "half_round.h"
 
 #include <algorithm>
 #include <atomic>
@@ -39,65 +40,6 @@ struct Ref {
 
 float kCostTraverse = 0.5f;   // one inner-record step (two slab tests)
 constexpr float kCostIntersect = 1.0f;   // one Moller-Trumbore test
-
-// ---- IEEE binary16 with directed rounding (host only; g++ 11 has no _Float16 on x86)
-float half_to_float(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-    const uint32_t em = h & 0x7fffu;
-    uint32_t bits;
-    float v;
-    if (em >= 0x7c00u) {                       // inf / nan
-        bits = sign | 0x7f800000u | ((em & 0x3ffu) << 13);
-        memcpy(&v, &bits, 4);
-        return v;
-    }
-    bits = em << 13;                           // exponent still biased by 15: scale by 2^(127-15)
-    memcpy(&v, &bits, 4);
-    v *= 0x1p112f;                             // exact; also turns half subnormals into the right floats
-    return sign ? -v : v;
-}
-uint16_t half_next_down(uint16_t h) {   // next representable value toward -inf (h finite or +inf)
-    if (h == 0x0000u) return 0x8001u;
-    return (h & 0x8000u) ? (uint16_t)(h + 1u) : (uint16_t)(h - 1u);
-}
-uint16_t half_next_up(uint16_t h) {     // toward +inf (h finite or -inf)
-    if (h == 0x8000u) return 0x0001u;
-    return (h & 0x8000u) ? (uint16_t)(h - 1u) : (uint16_t)(h + 1u);
-}
-uint16_t half_truncate(float f) {       // |result| <= |f| (round toward zero); |f| < 65520 assumed
-    uint32_t bits;
-    memcpy(&bits, &f, 4);
-    const uint16_t sign = (uint16_t)((bits >> 16) & 0x8000u);
-    const uint32_t a = bits & 0x7fffffffu;
-    if (a >= 0x38800000u) return sign | (uint16_t)((a >> 13) - (112u << 10));   // >= 2^-14: normal half
-    float m;
-    memcpy(&m, &a, 4);
-    return sign | (uint16_t)(uint32_t)(m * 0x1p24f);                            // subnormal half: units of 2^-24
-}
-uint16_t half_floor(double v) {         // largest half <= v
-    if (v >= 65504.0) return 0x7BFFu;
-    if (v < -65504.0) return 0xFC00u;
-    uint16_t h = half_truncate((float)v);
-    while ((double)half_to_float(h) > v) h = half_next_down(h);
-    for (;;) {                          // tighten: (float)v or the truncation may have stepped too far
-        const uint16_t up = half_next_up(h);
-        if (up == 0x7C00u || (double)half_to_float(up) > v) break;
-        h = up;
-    }
-    return h;
-}
-uint16_t half_ceil(double v) {          // smallest half >= v
-    if (v <= -65504.0) return 0xFBFFu;
-    if (v > 65504.0) return 0x7C00u;
-    uint16_t h = half_truncate((float)v);
-    while ((double)half_to_float(h) < v) h = half_next_up(h);
-    for (;;) {
-        const uint16_t dn = half_next_down(h);
-        if (dn == 0xFC00u || (double)half_to_float(dn) < v) break;
-        h = dn;
-    }
-    return h;
-}
 
 int levels_needed(size_t n) {  // inner-record levels a median-split subtree of n prims needs
     int l = 0;

@@ -152,6 +152,7 @@ public:
     bool Startup(const WindowT in_Window, const SceneT& in_Scene) override {
         (void)in_Window;
         if (trh_init(device_, &ctx_) != TRH_OK) return Fail("trh_init");
+        if (trh_set_builder(ctx_, builder_) != TRH_OK) return Fail("trh_set_builder");
         FlatScene flat;
         if (!FlattenScene(in_Scene, flat)) return Fail("FlattenScene");
         if (trh_scene_upload(ctx_, &flat.desc) != TRH_OK) return Fail("trh_scene_upload");
@@ -228,6 +229,8 @@ public:
     void SetTonemap(int in_Tonemap, float in_Exposure) { tonemap_ = in_Tonemap; exposure_ = in_Exposure; }
     // the reference's DEBUG_SHOW_* build switches (CMakeLists.txt:23-35) at run time; call before Startup or send eCameraCut
     void SetDebugView(int in_View) { debug_view_ = in_View; camera_dirty_ = ctx_ != nullptr; }
+    // acceleration-structure builder of the next Startup: TRH_BUILDER_HOST_SAH (default) or TRH_BUILDER_DEVICE_LBVH
+    void SetBuilder(int in_Builder) { builder_ = in_Builder; }
     uint32_t GetWidth() const { return width_; }
     uint32_t GetHeight() const { return height_; }
     uint32_t GetSampleCount() const { return next_sample_; }
@@ -259,6 +262,7 @@ private:
     int tonemap_ = TRH_TONEMAP_SRGB;   // default build: USE_TONEMAP_SRGB, TRACY_EXPOSURE 1
     float exposure_ = 1.f;
     int debug_view_ = TRH_VIEW_NONE;
+    int builder_ = TRH_BUILDER_HOST_SAH;
 };
 
 }  // namespace tracy_hip

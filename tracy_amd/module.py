@@ -24,7 +24,8 @@ class HipTrace:
     # TracyEvent (src/module.h:12)
     eCreate, eResize, eCameraCut, eDestroy = range(4)
 
-    def __init__(self, device=0, pipeline=None, spp_per_update=1, seed=DEFAULT_SEED):
+    def __init__(self, device=0, pipeline=None, spp_per_update=1, seed=DEFAULT_SEED, builder=None):
+        self.builder = builder   # capi.TRH_BUILDER_*; None = the library default (host SAH)
         self._lib = None
         self._ctx = C.c_void_p()
         self.device = device
@@ -46,6 +47,8 @@ class HipTrace:
         """bool Startup(const WindowHandle, const Scene&) (src/module.h:35)."""
         self._lib = capi.hip_lib()
         self._check(self._lib.trh_init(self.device, C.byref(self._ctx)))
+        if self.builder is not None:
+            self._check(self._lib.trh_set_builder(self._ctx, int(self.builder)))
         self._check(self._lib.trh_scene_upload(self._ctx, C.byref(scene.desc)))
         if self.pipeline is not None:
             self._check(self._lib.trh_set_pipeline(self._ctx, int(self.pipeline)))
@@ -155,6 +158,13 @@ class HipTrace:
         self._check(self._lib.trh_get_debug_counters(self._ctx, out, 10))
         return dict(zip(["wave_inner_iters", "wave_leaf_iters", "wave_shade_calls", "wave_gen_calls", "lanes_gen",
                          "cycles_inner", "cycles_leaf", "cycles_shade", "cycles_refill", "cycles_kernel"], list(out)))
+
+    def bvh_build_device(self, scene):
+        """trh_bvh_build_device: (info dict, layout hash, violations) of the device-side linear BVH of `scene`."""
+        b = capi.trh_bvh_info()
+        h, v = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.trh_bvh_build_device(self._ctx, C.byref(scene.desc), C.byref(b), C.byref(h), C.byref(v)))
+        return {k: getattr(b, k) for k, _ in capi.trh_bvh_info._fields_}, h.value, v.value
 
     def bvh_info(self):
         b = capi.trh_bvh_info()
