@@ -132,19 +132,22 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 d, float t, uint32_t id
 
 // ------------------------------------------------------------------ nearest hit
 // Resumable stack traversal of the BVH2 records (32-byte fp16 form, or the 64-byte fp32 fallback). The state lives in registers (Trav) plus
-// this lane's LDS stack column (entry i at stack[i * TRH_BLOCK]); a kernel may run trav_inner /
+// this lane's LDS stack column (row i at stack[i * TRH_BLOCK]); a kernel may run trav_inner /
 // trav_leaf for a while, do something else (shade other lanes, refill) and come back.
+// Row 0 of every column holds the sentinel -1 ("nothing left"), written once by the kernel: popping an empty
+// stack needs no special case, and the stack pointer is kept as the LDS address of the top row, so a step
+// reads the top at offset 0 and pushes at the immediate offset of one row -- no address arithmetic.
 struct Trav {
     V3 inv;      // rcp(direction) (src/ray.h:18) expressed in the BVH frame: 1 / (d * frame_s)
     V3 oi;       // (origin - frame_c) * rcp(direction): slab distance = fma(bound', inv, -oi)
     uint32_t selx, sely, selz;   // v_perm_b32 selectors: swap the (min | max << 16) halves of an axis word when d < 0
-    int node;    // >= 0: inner-node record; < -1: leaf link ~((first << 4) | count); -1: nothing to traverse
-    int sp;      // stack entries in use; < 0 <=> traversal finished
+    int node;    // >= 0: inner-node record; < -1: leaf link ~((first << 4) | count); -1: nothing to traverse (finished, or no ray)
+    int* top;    // this lane's top stack row (row 0 = the sentinel)
     Hit hit;
 };
-DEVFN bool trav_active(const Trav& tv) { return tv.sp >= 0; }
+DEVFN bool trav_active(const Trav& tv) { return tv.node != -1; }
 
-DEVFN void trav_begin(const DevScene& sc, Trav& tv, V3 o, V3 d) {
+DEVFN void trav_begin(const DevScene& sc, Trav& tv, V3 o, V3 d, int* __restrict__ stack) {
     // Node bounds live in the frame x' = (x - c) * s with s a power of two (c = 0, s = 1 for fp32 records), so
     // t = (x - o) / d = x' * (1 / (d s)) - (o - c) * (1 / d): one fma per plane, as before.
     // |1/d| is clamped so that the product with 1/s stays finite (only matters for s < 1, i.e. scenes
@@ -168,14 +171,13 @@ DEVFN void trav_begin(const DevScene& sc, Trav& tv, V3 o, V3 d) {
     // NaN direction (normalize(0) after total internal reflection, material.h:242-263): every RayAABB
     // comparison is false in the reference, i.e. a miss
     const bool nan = d.x != d.x;
-    tv.sp = nan ? -1 : 0;
+    tv.top = stack;
     tv.node = nan ? -1 : 0;
 }
 
-DEVFN void trav_pop(Trav& tv, const int* __restrict__ stack) {
-    --tv.sp;
-    const int top = stack[(tv.sp < 0 ? 0 : tv.sp) * TRH_BLOCK];
-    tv.node = tv.sp < 0 ? -1 : top;   // -1: traversal finished
+DEVFN void trav_pop(Trav& tv) {
+    tv.node = *tv.top;        // the sentinel -1 when nothing is left
+    tv.top -= TRH_BLOCK;
 }
 
 // one inner-node record: one fetch, two slab tests. Precondition: tv.node >= 0.
@@ -194,6 +196,9 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
     const V3 inv = tv.inv, oi = tv.oi;
     float tmin0, tmax0, tmin1, tmax1;
     int c0, c1;
+    // the entry a miss of both children would pop, read together with the record: its LDS latency hides behind the
+    // loads, and the step has no divergent pop branch (-2.5 % on the dragon against popping on demand)
+    const int top = *tv.top;
     if (N16) {
         const uint4 qa = sc.nodes16[tv.node * 2 + 0];
         const uint4 qb = sc.nodes16[tv.node * 2 + 1];
@@ -235,25 +240,20 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
     const bool h1 = tmin1 <= tmax1;
     const bool swp = h1 && (!h0 || tmin1 < tmin0);   // child 1 is the nearer (or the only) hit
     const int nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
-    stack[tv.sp * TRH_BLOCK] = farc;   // unconditional: slot sp is free; it only counts if both were hit
-    tv.sp += (h0 && h1) ? 1 : 0;
-    if (h0 || h1) tv.node = nearc;
-    else trav_pop(tv, stack);
+    tv.top[TRH_BLOCK] = farc;   // unconditional: the row above the top is free; it only counts if both were hit
+    const bool any = h0 || h1;
+    tv.node = any ? nearc : top;
+    tv.top += (h0 && h1) ? TRH_BLOCK : (any ? 0 : -TRH_BLOCK);
 }
 
 // ONE triangle of the current leaf: Moller-Trumbore on a 48-byte record (collision.h:33-74), then
 // advance inside the leaf link ((first + 1) << 4 | (count - 1)) or pop when the leaf is used up.
-// Precondition: tv.sp >= 0 && tv.node < 0.
+// Precondition: tv.node < -1.
 template <bool STATS>
 DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__ stack, Counters& cnt) {
-    uint32_t bits = ~(uint32_t)tv.node;
-#ifdef TRH_LEAF_WHOLE
-    for (; (bits & 15u) != 0u; bits += 15u) {
-        const uint32_t p = bits >> 4;
-#else
+    const uint32_t bits = ~(uint32_t)tv.node;
     const uint32_t p = bits >> 4;
     if ((bits & 15u) != 0u) {
-#endif
         const float4 r0 = sc.tris[p * 3 + 0];
         const float4 r1 = sc.tris[p * 3 + 1];
         const float4 r2 = sc.tris[p * 3 + 2];
@@ -280,18 +280,16 @@ DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__
             }
         }
     }
-#ifdef TRH_LEAF_WHOLE
-    trav_pop(tv, stack);
-#else
+    // (reading the stack top ahead, as trav_inner does, was measured here too: no gain, a leaf pops only once per leaf)
     if ((bits & 15u) > 1u) tv.node = (int)~(bits + 15u);
-    else trav_pop(tv, stack);
-#endif
+    else trav_pop(tv);
 }
 
 template <bool STATS, bool N16>
 DEVFN void intersect(const DevScene& sc, V3 o, V3 d, Hit& hit, int* __restrict__ stack, Counters& cnt) {
     Trav tv;
-    trav_begin(sc, tv, o, d);
+    stack[0] = -1;   // sentinel row
+    trav_begin(sc, tv, o, d, stack);
     while (trav_active(tv)) {
         while (tv.node >= 0) trav_inner<STATS, N16>(sc, o, tv, stack, cnt);
         if (trav_active(tv)) trav_leaf<STATS>(sc, o, d, tv, stack, cnt);

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define TRH_STACK_SIZE 32      // LDS traversal-stack entries per lane == bvh::kMaxDepth
+#define TRH_STACK_SIZE 32      // LDS traversal-stack entries per lane == bvh::kMaxDepth (the kernels add one sentinel row)
 #define TRH_BLOCK 256          // threads per workgroup (4 wave64)
 #define TRH_WAVES_PER_BLOCK (TRH_BLOCK / 64)
 #define TRH_MISS_ID 0xffffffffu
@@ -56,7 +56,7 @@ struct RenderParams {
     uint32_t seed32;          // pcg_hash of the folded 64-bit seed
     uint32_t tiles_x, tiles_y;
     uint32_t tile_w_log2, tile_h_log2;   // wave tile = (1 << tile_w_log2) x (1 << tile_h_log2) pixels
-    uint32_t stack_entries;   // LDS stack entries per lane (>= BVH depth)
+    uint32_t stack_entries;   // LDS stack rows per lane (BVH depth + the sentinel row)
     uint32_t refill_thresh;   // lanes waiting for shade/refill that end a traversal phase
     uint32_t sched_beta4;     // inner step is chosen when 4*n_inner >= sched_beta4*n_leaf (0 = while-while)
 };

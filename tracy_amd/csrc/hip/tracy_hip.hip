@@ -73,7 +73,7 @@ DEVFN void flush_counters(const Counters& c, DevCounters* g) {
 template <bool STATS, bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                                                                  DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
-    __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
+    __shared__ int s_stack[(TRH_STACK_SIZE + 1) * TRH_BLOCK];
     int* stack = &s_stack[threadIdx.x];
     const int lane = threadIdx.x & 63;
     const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
@@ -150,6 +150,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                                                           DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
     extern __shared__ int s_dyn[];
     int* stack = s_dyn + threadIdx.x;
+    stack[0] = -1;   // sentinel row of this lane's stack column (dev_trace.h)
     const int lane = threadIdx.x & 63;
     const uint32_t P_log2 = rp.tile_w_log2 + rp.tile_h_log2;
     const uint32_t P = 1u << P_log2;
@@ -178,7 +179,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
         tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
         tv.selx = tv.sely = tv.selz = 0x03020100u;
         tv.node = -1;
-        tv.sp = -1;
+        tv.top = stack;
         tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
         uint32_t pix = 0;           // pixel-in-tile of the item this lane works on
         bool has_path = false;      // a traversal result is waiting to be shaded
@@ -190,7 +191,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             if (has_path && !trav_active(tv)) {
                 const bool cont = shade<STATS>(sc, ps, tv.hit, cnt);
                 if (cont) {
-                    trav_begin(sc, tv, ps.o, ps.d);
+                    trav_begin(sc, tv, ps.o, ps.d, stack);
                 } else {
                     __hip_atomic_fetch_add(&wacc[pix * 3 + 0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&wacc[pix * 3 + 1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -215,7 +216,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                         if (px < sc.width && py < sc.height) {
                             if (STATS) { cnt.l_gen += 1; if (first_active_lane()) cnt.w_gen += 1; }
                             generate(sc, ps, px, py, sample, rp.seed32);
-                            trav_begin(sc, tv, ps.o, ps.d);
+                            trav_begin(sc, tv, ps.o, ps.d, stack);
                             has_path = true;
                         }   // else: pixel outside the frame (partial edge tile): the item is dropped
                     } else {
@@ -274,7 +275,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
 
 template <bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) void k_primary_hits(DevScene sc, uint32_t* __restrict__ ids, float* __restrict__ t_out, float2* __restrict__ uv_out) {
-    __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
+    __shared__ int s_stack[(TRH_STACK_SIZE + 1) * TRH_BLOCK];
     int* stack = &s_stack[threadIdx.x];
     const uint32_t p = blockIdx.x * TRH_BLOCK + threadIdx.x;
     if (p >= (uint32_t)(sc.width * sc.height)) return;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_primary_hits(DevScene sc, uint32_
 
 template <bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) void k_sample_radiance(DevScene sc, uint32_t sample, uint32_t seed_hash, float4* __restrict__ out) {
-    __shared__ int s_stack[TRH_STACK_SIZE * TRH_BLOCK];
+    __shared__ int s_stack[(TRH_STACK_SIZE + 1) * TRH_BLOCK];
     int* stack = &s_stack[threadIdx.x];
     const uint32_t p = blockIdx.x * TRH_BLOCK + threadIdx.x;
     if (p >= (uint32_t)(sc.width * sc.height)) return;
@@ -483,7 +484,7 @@ int launch_megakernel(trh_context* c, RenderParams rp) {
     rp.tile_h_log2 = hl;
     rp.tiles_x = ((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl;
     rp.tiles_y = ((uint32_t)c->sc.height + (1u << hl) - 1u) >> hl;
-    rp.stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u);
+    rp.stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u) + 1u;   // + the sentinel row
     rp.refill_thresh = c->refill_thresh;
     rp.sched_beta4 = c->sched_beta4;
     size_t lds = ((size_t)rp.stack_entries * TRH_BLOCK + (size_t)TRH_WAVES_PER_BLOCK * (3u << (wl + hl))) * 4;
@@ -547,7 +548,7 @@ int launch_wavefront(trh_context* c, const RenderParams& rp) {
     int rc = wf_ensure(c, (size_t)npix * batch_spp);
     if (rc) return rc;
     const uint32_t pool = c->wf.pool;
-    const uint32_t stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u);
+    const uint32_t stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u) + 1u;   // + the sentinel row
     const size_t lds = (size_t)stack_entries * TRH_BLOCK * 4;
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<N16>, TRH_BLOCK, lds));

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers 
     extern __shared__ int s_dyn[];
     (void)stack_entries;
     int* stack = s_dyn + threadIdx.x;
+    stack[0] = -1;   // sentinel row (dev_trace.h)
     const uint32_t n = wf.ctl->n_cur;
     Counters cnt = {};
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers 
     tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
     tv.selx = tv.sely = tv.selz = 0x03020100u;
     tv.node = -1;
-    tv.sp = -1;
+    tv.top = stack;
     tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
     uint32_t chunk_pos = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the queue
     bool queue_empty = false;                // wave-uniform: the last chunk fetch found the queue exhausted
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_wf_extend(DevScene sc, WfBuffers 
                     const float4 a = wf.st[slot * 5u + 0u], b = wf.st[slot * 5u + 1u];
                     o = mk(a.x, a.y, a.z);
                     d = mk(b.x, b.y, b.z);
-                    trav_begin(sc, tv, o, d);
+                    trav_begin(sc, tv, o, d, stack);
                     has_ray = true;
                 } else if (queue_empty) {
                     drained = true;
