@@ -200,8 +200,10 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
     // loads, and the step has no divergent pop branch (-2.5 % on the dragon against popping on demand)
     const int top = *tv.top;
     if (N16) {
-        const uint4 qa = sc.nodes16[tv.node * 2 + 0];
-        const uint4 qb = sc.nodes16[tv.node * 2 + 1];
+        // 32-bit byte offset from the (wave-uniform) array base: one shift, and the loads use the SGPR-base form
+        const uint4* rec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + ((uint32_t)tv.node << 5));
+        const uint4 qa = rec[0];
+        const uint4 qb = rec[1];
         // order the halves of every axis word by the ray's direction sign: low = entry plane, high = exit plane
         const H2 hx0 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qa.x, qa.x, tv.selx)), hy0 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qa.y, qa.y, tv.sely));
         const H2 hx1 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qa.z, qa.z, tv.selx)), hy1 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(qa.w, qa.w, tv.sely));
@@ -254,9 +256,14 @@ DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__
     const uint32_t bits = ~(uint32_t)tv.node;
     const uint32_t p = bits >> 4;
     if ((bits & 15u) != 0u) {
-        const float4 r0 = sc.tris[p * 3 + 0];
-        const float4 r1 = sc.tris[p * 3 + 1];
-        const float4 r2 = sc.tris[p * 3 + 2];
+        // 32-bit byte offset, as in trav_inner; 48 p as shift-adds (v_mul_lo_u32 runs at quarter rate; the empty asm keeps
+        // the compiler from folding the two steps back into a multiply)
+        uint32_t p3 = (p << 1) + p;
+        asm volatile("" : "+v"(p3));
+        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (p3 << 4));
+        const float4 r0 = rec[0];
+        const float4 r1 = rec[1];
+        const float4 r2 = rec[2];
         if (STATS) { cnt.tri_tests += 1; if (first_active_lane()) cnt.w_leaf += 1; }
         const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z);
         const uint32_t id = __float_as_uint(r0.w);
