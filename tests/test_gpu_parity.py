@@ -509,3 +509,20 @@ def test_random_cameras_against_oracle(oracle_mod, scene_loader, name):
         assert outliers <= 5e-3 * n
     finally:
         mod.Shutdown()
+
+
+def test_one_call_with_more_samples_than_one_launch_takes(hip, scene_loader):
+    """trh_render splits a call of more than 65536 spp into several launches: the image is the same as the
+    caller's own split, and every pixel counts every sample."""
+    sc = scene_loader("cornell", 4, 3)
+    a = hip(sc)
+    b = hip(sc)
+    n = 65536 + 1000
+    a.render(0, n)
+    b.render(0, 65536)
+    b.render(65536, 1000)
+    ia, na = a.resolve()
+    ib, nb = b.resolve()
+    assert na == nb == n and (ia[..., 3] == n).all()
+    assert np.array_equal(ia, ib)
+    assert a.stats()["samples"] == 4 * 3 * n

@@ -489,11 +489,14 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     hipLaunchKernelGGL(k_triangles, dim3(grid_n), dim3(kBlock), 0, stream, d_tris, d_prim, (uint32_t)n, d_out_tris);
     LB_TRY(hipGetLastError());
     Stats st{};
+    unsigned int unprocessed = 0;   // ranges queued below the last level: must be none (the depth guard)
     LB_TRY(hipMemcpyAsync(&st, d_stats, sizeof(st), hipMemcpyDeviceToHost, stream));
+    LB_TRY(hipMemcpyAsync(&unprocessed, d_counts + bvh::kMaxDepth + 2, sizeof(unprocessed), hipMemcpyDeviceToHost, stream));
     LB_TRY(hipEventRecord(e1, stream));
     LB_TRY(hipStreamSynchronize(stream));
     float ms = 0.f;
     LB_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (unprocessed != 0 || st.max_depth > (uint32_t)bvh::kMaxDepth) { err = "lbvh::build: tree deeper than the traversal stack"; return 2; }
 
     tmp.keep(d_nodes);
     tmp.keep(d_nodes16);

@@ -640,16 +640,26 @@ int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
-    int rc;
+    int rc = TRH_OK;
     const bool n16 = c->sc.nodes16 != nullptr;   // node record format of this scene (chosen at upload)
-    if (c->pipeline == TRH_PIPELINE_WAVEFRONT && !stats) rc = n16 ? launch_wavefront<true>(c, rp) : launch_wavefront<false>(c, rp);
-    else if (c->pipeline == TRH_PIPELINE_MEGAKERNEL_SIMPLE)
-        rc = stats ? (n16 ? launch_megakernel_simple<true, true>(c, rp) : launch_megakernel_simple<true, false>(c, rp))
-                   : (n16 ? launch_megakernel_simple<false, true>(c, rp) : launch_megakernel_simple<false, false>(c, rp));
-    else
-        rc = stats ? (n16 ? launch_megakernel<true, true>(c, rp) : launch_megakernel<true, false>(c, rp))
-                   : (n16 ? launch_megakernel<false, true>(c, rp) : launch_megakernel<false, false>(c, rp));
-    if (rc) return rc;
+    // one launch per 65536 samples per pixel at most: a tile's item count (pixels x samples) stays far inside 32 bits
+    constexpr uint32_t kMaxSppPerLaunch = 1u << 16;
+    for (uint32_t done = 0; done < spp_count && rc == TRH_OK; done += kMaxSppPerLaunch) {
+        rp.spp_begin = spp_begin + done;
+        rp.spp_count = std::min(kMaxSppPerLaunch, spp_count - done);
+        if (c->pipeline == TRH_PIPELINE_WAVEFRONT && !stats) rc = n16 ? launch_wavefront<true>(c, rp) : launch_wavefront<false>(c, rp);
+        else if (c->pipeline == TRH_PIPELINE_MEGAKERNEL_SIMPLE)
+            rc = stats ? (n16 ? launch_megakernel_simple<true, true>(c, rp) : launch_megakernel_simple<true, false>(c, rp))
+                       : (n16 ? launch_megakernel_simple<false, true>(c, rp) : launch_megakernel_simple<false, false>(c, rp));
+        else
+            rc = stats ? (n16 ? launch_megakernel<true, true>(c, rp) : launch_megakernel<true, false>(c, rp))
+                       : (n16 ? launch_megakernel<false, true>(c, rp) : launch_megakernel<false, false>(c, rp));
+    }
+    if (rc) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return rc;
+    }
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->pending.emplace_back(e0, e1);
     c->samples += (uint64_t)c->sc.width * c->sc.height * spp_count;
