@@ -26,6 +26,20 @@ def test_cli_reports_missing_scene():
     assert r.returncode != 0 and "Unable to load scene" in r.stderr
 
 
+def test_x11_viewer_is_built_and_fails_cleanly_without_a_display():
+    """tracy_hip_view (the interactive twin of win_raytracer.cpp's loop) links against X11 and the two libraries;
+    the boxes have no X server, so what can be checked is that it says so and exits before touching the GPU."""
+    view = os.path.join(ROOT, "tracy_amd", "lib", "tracy_hip_view")
+    if not os.path.exists("/usr/include/X11/Xlib.h"):
+        pytest.skip("no X11 development files: the viewer is not built")
+    assert os.path.exists(view), "run __graft_entry__.build()"
+    env = {k: v for k, v in os.environ.items() if k != "DISPLAY"}
+    r = subprocess.run([view, "-scene", os.path.join(ROOT, "assets/data/scenes/cornell.scn"), "-kernel", "hip"], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode != 0 and "cannot open display" in r.stderr
+    r = subprocess.run([view, "-kernel", "CUDA"], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode != 0 and "Invalid kernel choice" in r.stderr
+
+
 @pytest.mark.gpu
 def test_cli_renders_like_the_python_host(tmp_path):
     out = str(tmp_path / "cornell.pfm")

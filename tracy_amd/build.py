@@ -73,10 +73,24 @@ def build_cli(force=False):
     return out
 
 
+def build_view(force=False):
+    """Interactive X11 host (csrc/app/tracy_hip_view.cpp). Built where the X11 development files exist; there is
+    no X server on the GPU boxes, so only its start-up failure path is tested."""
+    if not os.path.exists("/usr/include/X11/Xlib.h"):
+        return None
+    out = os.path.join(LIB, "tracy_hip_view")
+    deps = _glob_deps(os.path.join(HERE, "csrc", "host"), os.path.join(HERE, "csrc", "app"), os.path.join(ROOT, "include"))
+    if force or _stale(out, deps):
+        _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", os.path.join(HERE, "csrc", "app", "tracy_hip_view.cpp"),
+              "-L", LIB, "-ltracy_hip", "-ltracy_scene", "-lX11", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", out])
+    return out
+
+
 def build_all(force=False):
     build_scene(force)
     build_hip(force)
     build_cli(force)
+    build_view(force)
 
 
 if __name__ == "__main__":
