@@ -6,8 +6,9 @@ for scene in sys.argv[1:] or ["dragon"]:
     sc = Scene(f"data/scenes/{scene}.scn", 1920, 1080)
     for pipe in (0, 2):
         mod = HipTrace(pipeline=pipe); mod.Startup(sc)
+        mod.render(0, 64); mod.synchronize()   # the first launch records the tile costs, the second runs cost-ordered
         mod.stats(reset=True)
-        mod.render(0, 64, stats=True)
+        mod.render(64, 64, stats=True)
         st = mod.stats(); d = mod.debug_counters()
         u_inner = (st["box_tests"] / 2) / (64 * max(1, d["wave_inner_iters"]))
         u_leaf = st["tri_tests"] / (64 * max(1, d["wave_leaf_iters"]))
@@ -18,6 +19,8 @@ for scene in sys.argv[1:] or ["dragon"]:
               f"| wave iters per ray*64: inner {d['wave_inner_iters']*64/st['rays']:.2f} leaf {d['wave_leaf_iters']*64/st['rays']:.2f} shade {d['wave_shade_calls']*64/st['rays']:.2f}")
         if d["cycles_kernel"]:
             k = d["cycles_kernel"]
+            if d.get("waves"):
+                print(f"   load balance: mean wave lifetime / longest = {k / d['waves'] / max(1, d['cycles_longest_wave']):.3f} ({d['waves']} waves)")
             rest = k - d["cycles_inner"] - d["cycles_leaf"] - d["cycles_shade"] - d["cycles_refill"]
             print(f"   wave time split: inner {d['cycles_inner']/k:.3f} leaf {d['cycles_leaf']/k:.3f} shade {d['cycles_shade']/k:.3f} refill+generate {d['cycles_refill']/k:.3f} votes/tile bookkeeping {rest/k:.3f}")
         mod.Shutdown()

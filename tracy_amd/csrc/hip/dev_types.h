@@ -59,6 +59,8 @@ struct RenderParams {
     uint32_t stack_entries;   // LDS stack rows per lane (BVH depth + the sentinel row)
     uint32_t refill_thresh;   // lanes waiting for shade/refill that end a traversal phase
     uint32_t sched_beta4;     // inner step is chosen when 4*n_inner >= sched_beta4*n_leaf (0 = while-while)
+    const uint32_t* tile_order;   // NULL: raster order; else the order the tile counter indexes (tile_order.h)
+    uint32_t* tile_cost;          // NULL, or per-tile shader-clock ticks of this launch (input of the next launch's order)
 };
 
 // device-side counters, one cache line
@@ -69,4 +71,6 @@ struct DevCounters {
     unsigned long long wave_inner_iters, wave_leaf_iters, wave_shade_calls, wave_gen_calls, lanes_gen;
     // shader-clock cycles the waves spent per phase (instrumented kernel only): inner steps, triangle steps, shade, refill/generate, whole kernel
     unsigned long long phase_cycles[5];
+    unsigned long long max_wave_cycles;   // instrumented kernel only: the longest-lived wave (load balance = mean / max)
+    unsigned long long waves;             // instrumented kernel only: waves that reported
 };

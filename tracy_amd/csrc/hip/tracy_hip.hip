@@ -17,6 +17,7 @@
 #include "../../../include/tracy_hip.h"
 #include "../host/bvh_builder.h"
 #include "lbvh_build.h"
+#include "tile_order.h"
 #include "dev_trace.h"
 
 #include <algorithm>
@@ -62,6 +63,8 @@ DEVFN void flush_counters(const Counters& c, DevCounters* g) {
             atomicAdd(&g->wave_gen_calls, (unsigned long long)e);
             atomicAdd(&g->lanes_gen, (unsigned long long)f);
             for (int k = 0; k < 5; ++k) atomicAdd(&g->phase_cycles[k], c.cyc[k]);
+            atomicMax(&g->max_wave_cycles, c.cyc[4]);
+            atomicAdd(&g->waves, 1ull);
         }
     }
 }
@@ -165,6 +168,8 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
         if (lane == 0) tile = atomicAdd(tile_counter, 1u);
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile >= ntiles) break;  // wave-uniform exit: every wave reaches it
+        if (rp.tile_order) tile = __builtin_amdgcn_readfirstlane(rp.tile_order[tile]);   // expensive tiles first (tile_order.h)
+        const unsigned long long t_tile = rp.tile_cost ? __builtin_readcyclecounter() : 0ull;
         const int tile_x0 = (int)((tile % rp.tiles_x) << rp.tile_w_log2);
         const int tile_y0 = (int)((tile / rp.tiles_x) << rp.tile_h_log2);
         for (uint32_t i = lane; i < P * 3; i += 64) wacc[i] = 0.f;
@@ -268,6 +273,10 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (rp.tile_cost && lane == 0) {
+            const unsigned long long dt = __builtin_readcyclecounter() - t_tile;
+            rp.tile_cost[tile] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+        }
     }
     if (STATS) cnt.cyc[4] += __builtin_readcyclecounter() - t_kernel;
     flush_counters<STATS>(cnt, counters);
@@ -398,6 +407,13 @@ struct trh_context {
     uint32_t* bitmap = nullptr;       // BGRA8 picture of trh_present_bgra8
     DevCounters* counters = nullptr;
     unsigned int* tile_counter = nullptr;
+    // cost-ordered tile scheduling (tile_order.h); the arrays live until the next scene upload
+    bool tile_feedback = true;
+    bool tile_order_valid = false;
+    uint32_t tile_count = 0, tile_shape = 0;   // the tiling the arrays below belong to
+    uint32_t *tile_cost = nullptr, *tile_order = nullptr, *tile_keys = nullptr, *tile_keys_sorted = nullptr, *tile_iota = nullptr;
+    void* tile_scratch = nullptr;
+    size_t tile_scratch_bytes = 0;
     uint64_t samples = 0;        // since the last stats reset
     uint64_t accum_spp = 0;      // samples per pixel in the accumulation buffer
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // render launches not yet timed
@@ -439,6 +455,10 @@ int free_scene(trh_context* c) {
     c->accum_internal = nullptr;
     c->resolved = nullptr;
     c->bitmap = nullptr;
+    c->tile_cost = c->tile_order = c->tile_keys = c->tile_keys_sorted = c->tile_iota = nullptr;
+    c->tile_scratch = nullptr;
+    c->tile_count = 0;
+    c->tile_order_valid = false;
     c->has_scene = false;
     return TRH_OK;
 }
@@ -475,11 +495,44 @@ int launch_megakernel_simple(trh_context* c, RenderParams rp) {
     return TRH_OK;
 }
 
+// (re)allocates the tile-order arrays for a tiling of ntiles tiles; a new tiling starts in raster order
+int ensure_tile_order(trh_context* c, uint32_t ntiles, uint32_t shape) {
+    if (c->tile_count == ntiles && c->tile_shape == shape && c->tile_cost) return TRH_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    void** arrays[6] = {(void**)&c->tile_cost, (void**)&c->tile_order, (void**)&c->tile_keys, (void**)&c->tile_keys_sorted, (void**)&c->tile_iota, &c->tile_scratch};
+    for (void** a : arrays) {
+        if (*a) {
+            c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), *a), c->allocs.end());
+            (void)hipFree(*a);
+            *a = nullptr;
+        }
+    }
+    c->tile_order_valid = false;
+    c->tile_count = 0;
+    c->tile_scratch_bytes = tile_order::scratch_bytes(ntiles);
+    for (int k = 0; k < 6; ++k) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, k < 5 ? (size_t)ntiles * sizeof(uint32_t) : std::max<size_t>(c->tile_scratch_bytes, 16)));
+        c->allocs.push_back(p);
+        *arrays[k] = p;
+    }
+    HIP_TRY(hipMemsetAsync(c->tile_cost, 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
+    c->tile_count = ntiles;
+    c->tile_shape = shape;
+    return TRH_OK;
+}
+
 template <bool STATS, bool N16>
 int launch_megakernel(trh_context* c, RenderParams rp) {
-    // tile = 8x8 pixels x spp items; with few samples per call use 16x16 pixels so that a wave still
-    // has several items per lane to schedule
-    const uint32_t wl = rp.spp_count >= 8 ? 3u : 4u, hl = wl;
+    // tile = P pixels x spp items. A tile should hold enough items for the wave-local scheduler to keep its lanes busy
+    // (>= 256, best around 2048 = 32 per lane) and the launch enough tiles to balance (>= 8 per resident wave):
+    // measured on the dragon at 64 spp, 8x8 pixels 15.9 ms, 8x4 13.3 ms, 4x4 13.6 ms, 16x4 15.6 ms.
+    const uint64_t total_items = (uint64_t)c->sc.width * (uint64_t)c->sc.height * rp.spp_count;
+    const uint64_t resident_waves = (uint64_t)c->num_cus * 16u;
+    const uint64_t target = std::min<uint64_t>(2048u, std::max<uint64_t>(256u, total_items / (resident_waves * 8u)));
+    uint32_t p_log2 = 2;   // 2x2 ... 16x16 pixels: the largest power of two with P * spp <= target
+    while (p_log2 < 8u && (uint64_t)(2u << p_log2) * rp.spp_count <= target) ++p_log2;
+    const uint32_t wl = (p_log2 + 1u) / 2u, hl = p_log2 / 2u;
     rp.tile_w_log2 = wl;
     rp.tile_h_log2 = hl;
     rp.tiles_x = ((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl;
@@ -487,6 +540,16 @@ int launch_megakernel(trh_context* c, RenderParams rp) {
     rp.stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u) + 1u;   // + the sentinel row
     rp.refill_thresh = c->refill_thresh;
     rp.sched_beta4 = c->sched_beta4;
+    // cost-ordered tiles: this launch records what every tile cost, the next launch of the same tiling hands the
+    // tiles out most expensive class first. Launches of a few samples (16x16-pixel tiles) keep raster order: the
+    // re-sort would cost a noticeable part of a 1 ms launch.
+    const bool ordered = c->tile_feedback && rp.spp_count >= 8;
+    if (ordered) {
+        const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
+        if (int orc = ensure_tile_order(c, ntiles, (wl << 8) | hl)) return orc;
+        rp.tile_order = c->tile_order_valid ? c->tile_order : nullptr;
+        rp.tile_cost = c->tile_cost;
+    }
     size_t lds = ((size_t)rp.stack_entries * TRH_BLOCK + (size_t)TRH_WAVES_PER_BLOCK * (3u << (wl + hl))) * 4;
     lds += c->lds_pad;   // development knob: lowers occupancy to measure latency sensitivity
     int per_cu = 0;
@@ -496,6 +559,12 @@ int launch_megakernel(trh_context* c, RenderParams rp) {
     HIP_TRY(hipMemsetAsync(c->tile_counter, 0, sizeof(unsigned int), c->stream));
     hipLaunchKernelGGL((k_megakernel<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
     HIP_TRY(hipGetLastError());
+    if (ordered) {
+        const int e = tile_order::sort_by_cost(c->tile_cost, c->tile_order, c->tile_count, c->tile_keys, c->tile_keys_sorted, c->tile_iota, c->tile_scratch,
+                                               c->tile_scratch_bytes, c->stream);
+        if (e != 0) return fail(TRH_ERR_HIP, std::string("tile_order::sort_by_cost: ") + hipGetErrorString((hipError_t)e));
+        c->tile_order_valid = true;
+    }
     return TRH_OK;
 }
 
@@ -714,6 +783,7 @@ int trh_init(int device, trh_context** ctx_out) {
         if (v >= 8 && v <= 26) c->wf_pool_limit = 1u << v;
     }
     if (const char* e = getenv("TRH_LDS_PAD")) c->lds_pad = (size_t)atoi(e);
+    if (const char* e = getenv("TRH_TILE_FEEDBACK")) c->tile_feedback = atoi(e) != 0;   // development knob: 0 = raster order always
     if (const char* e = getenv("TRH_BUILDER")) c->builder = strcmp(e, "lbvh") == 0 ? TRH_BUILDER_DEVICE_LBVH : TRH_BUILDER_HOST_SAH;   // default builder of this context
     if (const char* e = getenv("TRH_SCHED_BETA4")) {     // development knob
         const int v = atoi(e);
@@ -1172,9 +1242,9 @@ int trh_get_debug_counters(trh_context* c, uint64_t* out, uint32_t n) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     DevCounters h{};
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
-    const uint64_t v[10] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen,
-                            h.phase_cycles[0], h.phase_cycles[1], h.phase_cycles[2], h.phase_cycles[3], h.phase_cycles[4]};
-    for (uint32_t i = 0; i < n; ++i) out[i] = i < 10 ? v[i] : 0;
+    const uint64_t v[12] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen,
+                            h.phase_cycles[0], h.phase_cycles[1], h.phase_cycles[2], h.phase_cycles[3], h.phase_cycles[4], h.max_wave_cycles, h.waves};
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 12 ? v[i] : 0;
     return TRH_OK;
 }
 
