@@ -421,7 +421,7 @@ struct trh_context {
     uint64_t launches = 0;
     trh_bvh_info bvh{};
     int simple_grid[2][2] = {{0, 0}, {0, 0}};
-    uint32_t refill_thresh = 24;
+    uint32_t refill_thresh = 40;   // swept 16..48 with the cost-ordered 2048-item tiles
     uint32_t sched_beta4 = 6;
     size_t lds_pad = 0;
     // wavefront pipeline state (allocated on first use)
