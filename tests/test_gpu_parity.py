@@ -526,3 +526,37 @@ def test_one_call_with_more_samples_than_one_launch_takes(hip, scene_loader):
     assert na == nb == n and (ia[..., 3] == n).all()
     assert np.array_equal(ia, ib)
     assert a.stats()["samples"] == 4 * 3 * n
+
+
+def test_tile_order_does_not_change_the_image(scene_loader, monkeypatch):
+    """Cost-ordered tiles (tile_order.h) and the probe sample of a first launch only change WHEN a tile runs:
+    launches of 8 spp (ordered from the second launch on, no probe) are bit-identical with the feature off, and
+    a first launch of 64 spp (1 probe sample + 63 ordered) equals the same samples on a context that already
+    has an order up to the rounding of the per-pixel sums."""
+    from tracy_amd import HipTrace
+    sc = scene_loader("dragon", 480, 270)
+
+    def three_launches(feedback):
+        monkeypatch.setenv("TRH_TILE_FEEDBACK", feedback)
+        m = HipTrace()
+        m.Startup(sc)
+        for k in range(3):
+            m.render(8 * k, 8)
+        img, n = m.resolve()
+        m.Shutdown()
+        return img, n
+    on, n_on = three_launches("1")
+    off, n_off = three_launches("0")
+    assert n_on == n_off == 24 and np.array_equal(on, off)
+
+    monkeypatch.setenv("TRH_TILE_FEEDBACK", "1")
+    fresh = HipTrace()
+    fresh.Startup(sc)
+    fresh.render(0, 64)                     # probe sample + 63
+    a, na = fresh.resolve()
+    fresh.reset()
+    fresh.render(0, 64)                     # the tiling now has an order: one launch of 64
+    b, nb = fresh.resolve()
+    fresh.Shutdown()
+    assert na == nb == 64 and (a[..., 3] == 64).all() and (b[..., 3] == 64).all()
+    assert np.allclose(a[..., :3], b[..., :3], rtol=2e-6, atol=1e-7)

@@ -522,17 +522,9 @@ int ensure_tile_order(trh_context* c, uint32_t ntiles, uint32_t shape) {
     return TRH_OK;
 }
 
+// one launch of the megakernel with the tiling (wl, hl)
 template <bool STATS, bool N16>
-int launch_megakernel(trh_context* c, RenderParams rp) {
-    // tile = P pixels x spp items. A tile should hold enough items for the wave-local scheduler to keep its lanes busy
-    // (>= 256, best around 2048 = 32 per lane) and the launch enough tiles to balance (>= 8 per resident wave):
-    // measured on the dragon at 64 spp, 8x8 pixels 15.9 ms, 8x4 13.3 ms, 4x4 13.6 ms, 16x4 15.6 ms.
-    const uint64_t total_items = (uint64_t)c->sc.width * (uint64_t)c->sc.height * rp.spp_count;
-    const uint64_t resident_waves = (uint64_t)c->num_cus * 16u;
-    const uint64_t target = std::min<uint64_t>(2048u, std::max<uint64_t>(256u, total_items / (resident_waves * 8u)));
-    uint32_t p_log2 = 2;   // 2x2 ... 16x16 pixels: the largest power of two with P * spp <= target
-    while (p_log2 < 8u && (uint64_t)(2u << p_log2) * rp.spp_count <= target) ++p_log2;
-    const uint32_t wl = (p_log2 + 1u) / 2u, hl = p_log2 / 2u;
+int launch_megakernel_tiled(trh_context* c, RenderParams rp, uint32_t wl, uint32_t hl, bool ordered) {
     rp.tile_w_log2 = wl;
     rp.tile_h_log2 = hl;
     rp.tiles_x = ((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl;
@@ -540,10 +532,6 @@ int launch_megakernel(trh_context* c, RenderParams rp) {
     rp.stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u) + 1u;   // + the sentinel row
     rp.refill_thresh = c->refill_thresh;
     rp.sched_beta4 = c->sched_beta4;
-    // cost-ordered tiles: this launch records what every tile cost, the next launch of the same tiling hands the
-    // tiles out most expensive class first. Launches of a few samples (16x16-pixel tiles) keep raster order: the
-    // re-sort would cost a noticeable part of a 1 ms launch.
-    const bool ordered = c->tile_feedback && rp.spp_count >= 8;
     if (ordered) {
         const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
         if (int orc = ensure_tile_order(c, ntiles, (wl << 8) | hl)) return orc;
@@ -566,6 +554,35 @@ int launch_megakernel(trh_context* c, RenderParams rp) {
         c->tile_order_valid = true;
     }
     return TRH_OK;
+}
+
+template <bool STATS, bool N16>
+int launch_megakernel(trh_context* c, RenderParams rp) {
+    // tile = P pixels x spp items. A tile should hold enough items for the wave-local scheduler to keep its lanes busy
+    // (>= 256, best around 2048 = 32 per lane) and the launch enough tiles to balance (>= 8 per resident wave):
+    // measured on the dragon at 64 spp, 8x8 pixels 15.9 ms, 8x4 13.3 ms, 4x4 13.6 ms, 16x4 15.6 ms.
+    const uint64_t total_items = (uint64_t)c->sc.width * (uint64_t)c->sc.height * rp.spp_count;
+    const uint64_t resident_waves = (uint64_t)c->num_cus * 16u;
+    const uint64_t target = std::min<uint64_t>(2048u, std::max<uint64_t>(256u, total_items / (resident_waves * 8u)));
+    uint32_t p_log2 = 2;   // 2x2 ... 16x16 pixels: the largest power of two with P * spp <= target
+    while (p_log2 < 8u && (uint64_t)(2u << p_log2) * rp.spp_count <= target) ++p_log2;
+    const uint32_t wl = (p_log2 + 1u) / 2u, hl = p_log2 / 2u;
+    // cost-ordered tiles (tile_order.h): a launch records what every tile cost, the next launch of the same tiling
+    // hands the tiles out most expensive first. Launches of a few samples keep raster order: the re-sort would cost a
+    // noticeable part of a 1 ms launch.
+    const bool ordered = c->tile_feedback && rp.spp_count >= 8;
+    // The first launch of a tiling has no costs yet: its first sample is traced as a launch of its own, in raster
+    // order, and its tile costs order the rest (dragon, 64 spp on a fresh context: 14.5 ms instead of 21).
+    const bool have_order = c->tile_order_valid && c->tile_count == (((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl) * (((uint32_t)c->sc.height + (1u << hl) - 1u) >> hl) &&
+                            c->tile_shape == ((wl << 8) | hl);
+    if (ordered && !have_order && rp.spp_count >= 16) {
+        RenderParams probe = rp;
+        probe.spp_count = 1;
+        if (int prc = launch_megakernel_tiled<STATS, N16>(c, probe, wl, hl, true)) return prc;
+        rp.spp_begin += 1;
+        rp.spp_count -= 1;
+    }
+    return launch_megakernel_tiled<STATS, N16>(c, rp, wl, hl, ordered);
 }
 
 // ---------------------------------------------------------------------------------------
