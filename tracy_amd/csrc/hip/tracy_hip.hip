@@ -558,14 +558,18 @@ int launch_megakernel_tiled(trh_context* c, RenderParams rp, uint32_t wl, uint32
 
 template <bool STATS, bool N16>
 int launch_megakernel(trh_context* c, RenderParams rp) {
-    // tile = P pixels x spp items. A tile should hold enough items for the wave-local scheduler to keep its lanes busy
-    // (>= 256, best around 2048 = 32 per lane) and the launch enough tiles to balance (>= 8 per resident wave):
-    // measured on the dragon at 64 spp, 8x8 pixels 15.9 ms, 8x4 13.3 ms, 4x4 13.6 ms, 16x4 15.6 ms.
-    const uint64_t total_items = (uint64_t)c->sc.width * (uint64_t)c->sc.height * rp.spp_count;
-    const uint64_t resident_waves = (uint64_t)c->num_cus * 16u;
-    const uint64_t target = std::min<uint64_t>(2048u, std::max<uint64_t>(256u, total_items / (resident_waves * 8u)));
-    uint32_t p_log2 = 2;   // 2x2 ... 16x16 pixels: the largest power of two with P * spp <= target
-    while (p_log2 < 8u && (uint64_t)(2u << p_log2) * rp.spp_count <= target) ++p_log2;
+    // tile = P pixels x spp items, P = 2x2 ... 16x16 pixels. Two wishes pull on P: a tile should hold enough items for
+    // the wave-local scheduler to keep its lanes busy (best about 2048 = 32 per lane, no use below 512), and the launch
+    // should have about 16 tiles per resident wave to balance. Measured on the dragon at 1080p (32400 tiles of 64
+    // pixels = 7.9 per wave): 64 spp: 8x8 pixels 15.9 ms, 8x4 13.0, 4x4 13.6; 32 spp: 8x8 8.3, 8x4 7.1; 16 spp: 4.3 / 4.0;
+    // 8 spp: 2.44 / 2.56; 1 spp: 16x16 pixels 1.01 ms, 16x8 0.84, 8x8 0.77.
+    const double pixels = (double)c->sc.width * (double)c->sc.height;
+    const double resident_waves = (double)c->num_cus * 16.0;
+    const double p_wish = std::min(2048.0 / (double)rp.spp_count, pixels / (resident_waves * 16.0));
+    uint32_t p_log2 = 2;
+    while (p_log2 < 8u && (double)(2u << p_log2) <= p_wish * 1.4142135) ++p_log2;   // nearest power of two
+    // few samples: rather 512 items per tile than 16 tiles per wave, down to 4 tiles per wave
+    while (p_log2 < 8u && (uint64_t)(1u << p_log2) * rp.spp_count < 512u && pixels / (double)(2u << p_log2) >= resident_waves * 4.0) ++p_log2;
     const uint32_t wl = (p_log2 + 1u) / 2u, hl = p_log2 / 2u;
     // cost-ordered tiles (tile_order.h): a launch records what every tile cost, the next launch of the same tiling
     // hands the tiles out most expensive first. Launches of a few samples keep raster order: the re-sort would cost a
