@@ -135,7 +135,7 @@ int trh_scene_upload(trh_context* ctx, const trh_scene_desc* scene);
 /* Which builder trh_scene_upload uses for the acceleration structure (call before the upload):
  * the host-side binned-SAH build (default: best traversal speed, tens of ms per 100k triangles on the
  * host cores) or the device-side linear BVH (Morton sort + Karras hierarchy on the GPU: milliseconds
- * for millions of triangles, but 25-40 % slower to traverse). Both emit the same record formats and leaf
+ * for millions of triangles, but 10-35 % slower to traverse). Both emit the same record formats and leaf
  * links, so every kernel runs unchanged. Scenes of < 9 triangles, and trees the linear build makes
  * deeper than the traversal stack (32), are built by the host builder whatever the setting;
  * trh_bvh_info.builder tells which one built the resident structure. No counterpart in the
@@ -176,7 +176,13 @@ int trh_set_debug_view(trh_context* ctx, int view /* trh_debug_view */, const fl
  * their radiance into the context's float4 accumulation buffer (rgb sum, .w = count).
  * RNG state of sample s of pixel p is derived from (p, s, seed), then follows the
  * reference's PCG fastrand sequence (src/random.h:66-77). Asynchronous on the context's
- * stream; trh_synchronize / trh_resolve / trh_get_stats wait for it. */
+ * stream; trh_synchronize / trh_resolve / trh_get_stats wait for it.
+ * Scheduling only (never the samples traced): a call of more than 65536 spp is split into several
+ * launches; every launch records what each screen tile cost and the next launch of the same tiling
+ * starts with the expensive tiles; the first launch of >= 16 spp after a scene upload or a change of
+ * the sample count traces its first sample as a launch of its own to get those costs. The order of
+ * the float additions into a pixel therefore depends on the history of calls -- the same sequence of
+ * calls gives the same bits, different sequences agree to rounding. */
 int trh_render(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, uint64_t seed);
 
 /* Same as trh_render but runs the instrumented kernel build that also counts box tests,

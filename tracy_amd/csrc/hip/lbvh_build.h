@@ -4,7 +4,7 @@
 // and its CUDA module has no acceleration structure at all (cuda_trace.cu:22-46). The default builder
 // of this module is the host-side binned-SAH build (bvh_builder.h); this is the alternative for
 // scenes whose start-up time matters more than traversal speed (measured: 1.6 M triangles in 11 ms
-// instead of 340 ms; the render is 25-40 % slower): a linear BVH built entirely on the GPU -- 63-bit
+// instead of 340 ms; the render is 10-35 % slower): a linear BVH built entirely on the GPU -- 63-bit
 // Morton codes of the triangle centroids, one radix sort, a top-down pass per tree level that splits
 // every range where its highest differing code bit flips (with the host builder's depth guard), a
 // bottom-up box fit, ranges of <= 4 triangles as leaves, records compacted and emitted directly in
