@@ -560,3 +560,35 @@ def test_tile_order_does_not_change_the_image(scene_loader, monkeypatch):
     fresh.Shutdown()
     assert na == nb == 64 and (a[..., 3] == 64).all() and (b[..., 3] == 64).all()
     assert np.allclose(a[..., :3], b[..., :3], rtol=2e-6, atol=1e-7)
+
+
+def test_scene_reupload_on_a_live_context(scene_loader):
+    """trh_scene_upload may be called again on a context that has rendered (another scene, another frame size,
+    another builder): every per-scene array -- BVH, accumulators, tile costs and order -- is rebuilt, and the
+    context then renders exactly what a fresh one does."""
+    import ctypes as C
+    from tracy_amd import HipTrace, capi
+    a, b = scene_loader("dragon", 192, 108), scene_loader("cornell", 64, 36)
+    mod = HipTrace()
+    mod.Startup(a)
+    for k in range(3):
+        mod.render(16 * k, 16)                      # builds up a tile order for the first tiling
+    mod.synchronize()
+    for builder in (capi.TRH_BUILDER_HOST_SAH, capi.TRH_BUILDER_DEVICE_LBVH):
+        assert mod._lib.trh_set_builder(mod._ctx, builder) == 0
+        assert mod._lib.trh_scene_upload(mod._ctx, C.byref(b.desc)) == 0
+        mod.width, mod.height = b.width, b.height
+        mod._upload_camera(b)
+        assert mod.bvh_info()["builder"] == builder
+        for k in range(2):
+            mod.render(16 * k, 16)
+        img, n = mod.resolve()
+        fresh = HipTrace(builder=builder)
+        fresh.Startup(b)
+        for k in range(2):
+            fresh.render(16 * k, 16)
+        want, n2 = fresh.resolve()
+        fresh.Shutdown()
+        assert n == n2 == 32 and img.shape == want.shape == (36, 64, 4)
+        assert np.array_equal(img, want)
+    mod.Shutdown()
