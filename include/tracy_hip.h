@@ -258,7 +258,7 @@ typedef struct trh_bvh_info {
     double   build_ms;
     double   fp16_inflation;  /* box-area growth of the 32-byte fp16 records; node_bytes / node_count tells which format is in use */
     uint32_t builder;         /* trh_builder that produced it */
-    uint32_t reserved;
+    uint32_t from_cache;      /* 1: read from the on-disk cache (trh_set_bvh_cache_dir) instead of built */
     double   device_build_ms; /* device LBVH only: HIP-event time of its kernels + sort (build_ms is the wall time incl. the upload) */
 } trh_bvh_info;
 int trh_get_bvh_info(trh_context* ctx, trh_bvh_info* out);
@@ -271,6 +271,14 @@ int trh_get_bvh_info(trh_context* ctx, trh_bvh_info* out);
  * number of builder threads (TRH_BUILD_THREADS). No counterpart in the reference (its kd-tree build,
  * kdtree.h:160-354, is not what the kernels traverse). */
 int trh_bvh_build_host(const trh_scene_desc* scene, trh_bvh_info* info_out, uint64_t* hash_out, uint64_t* violations_out);
+
+/* On-disk cache of host-built acceleration structures, process-wide: with a directory set, trh_scene_upload
+ * and trh_bvh_build_host look there for a file named after a hash of the scene's triangles and use it instead
+ * of building (after checking its header, sizes, checksum and the structural self-check above); on a miss they
+ * build and write the file. NULL or "" switches the cache off (the default; the environment variable
+ * TRH_BVH_CACHE sets the initial directory). The device-side builder does not use it. No counterpart in the
+ * reference (it rebuilds its kd-tree at every start, cpu_details.cpp:26-86). */
+int trh_set_bvh_cache_dir(const char* directory);
 
 /* The same check for the device-side builder: builds the linear BVH of the scene on ctx's device, copies
  * the arrays back and runs the same structural self-check and hash on them. Leaves the context's resident

@@ -110,3 +110,61 @@ def test_invalid_descriptions_are_rejected():
     d, keep = make_desc([(0, 0, 0), (1, 0, 0), (0, 1, 0)], [0, 1, 7])   # vertex index out of range
     assert lib.trh_bvh_build_host(C.byref(d), None, None, C.byref(bad)) != 0
     assert b"out of range" in lib.trh_last_error()
+
+
+def test_on_disk_cache(scene_loader, tmp_path):
+    """trh_set_bvh_cache_dir: a second build of the same scene is read from the file (same arrays, hash-equal), a
+    different scene gets its own file, and a damaged or truncated file is ignored and rewritten, never trusted."""
+    import glob
+    import os
+    lib = capi.hip_lib()
+    sc, other = scene_loader("dragon", 64, 36), scene_loader("bunny", 64, 36)
+    _, h_plain, bad, why = build_host(sc.desc)
+    assert bad == 0, why
+    try:
+        assert lib.trh_set_bvh_cache_dir(str(tmp_path).encode()) == 0
+        info1, h1, bad1, _ = build_host(sc.desc)
+        files = glob.glob(str(tmp_path / "*.trhbvh"))
+        assert info1.from_cache == 0 and bad1 == 0 and h1 == h_plain and len(files) == 1
+        info2, h2, bad2, _ = build_host(sc.desc)
+        assert info2.from_cache == 1 and bad2 == 0 and h2 == h_plain
+        assert (info2.node_count, info2.max_depth, info2.max_leaf_size) == (info1.node_count, info1.max_depth, info1.max_leaf_size)
+        assert info2.fp16_inflation == info1.fp16_inflation and info2.sah_cost == info1.sah_cost
+        info3, _, bad3, _ = build_host(other.desc)
+        assert info3.from_cache == 0 and bad3 == 0 and len(glob.glob(str(tmp_path / "*.trhbvh"))) == 2
+        # flip one byte in the middle of the node records: checksum mismatch -> rebuilt and rewritten
+        path = files[0]
+        size = os.path.getsize(path)
+        with open(path, "r+b") as f:
+            f.seek(96 + 4000)
+            b = f.read(1)
+            f.seek(96 + 4000)
+            f.write(bytes([b[0] ^ 0x40]))
+        info4, h4, bad4, _ = build_host(sc.desc)
+        assert info4.from_cache == 0 and bad4 == 0 and h4 == h_plain and os.path.getsize(path) == size
+        assert build_host(sc.desc)[0].from_cache == 1
+        # truncated file
+        with open(path, "r+b") as f:
+            f.truncate(size // 2)
+        info5, h5, bad5, _ = build_host(sc.desc)
+        assert info5.from_cache == 0 and bad5 == 0 and h5 == h_plain
+        # a file with a valid checksum over WRONG links must not get through: swap two child links of the root record
+        with open(path, "r+b") as f:
+            raw = bytearray(f.read())
+        n_nodes_f32 = int.from_bytes(raw[16:24], "little")
+        root_links = 96 + 12 * 4
+        raw[root_links:root_links + 4] = (0x7FFFFFF0).to_bytes(4, "little")        # an inner link far out of range (fp32 record)
+        q = 96 + n_nodes_f32 * 4 + 6 * 4
+        raw[q:q + 4] = (0x7FFFFFF0).to_bytes(4, "little")                           # and in the fp16 record
+        # recompute the file's checksum the way the builder does (FNV-1a over the four arrays)
+        hsh = 1469598103934665603
+        for byte in raw[96:]:
+            hsh = ((hsh ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        raw[88:96] = hsh.to_bytes(8, "little")
+        with open(path, "wb") as f:
+            f.write(raw)
+        info6, h6, bad6, _ = build_host(sc.desc)
+        assert info6.from_cache == 0 and bad6 == 0 and h6 == h_plain, "a structurally wrong cache file was trusted"
+    finally:
+        lib.trh_set_bvh_cache_dir(None)
+    assert build_host(sc.desc)[0].from_cache == 0

@@ -594,3 +594,22 @@ def test_scene_reupload_on_a_live_context(scene_loader):
         assert n == n2 == 32 and img.shape == want.shape == (36, 64, 4)
         assert np.array_equal(img, want)
     mod.Shutdown()
+
+
+def test_upload_from_the_bvh_cache_renders_the_same(scene_loader, tmp_path):
+    from tracy_amd import HipTrace, capi
+    lib = capi.hip_lib()
+    sc = scene_loader("spheres", 96, 54)
+    try:
+        assert lib.trh_set_bvh_cache_dir(str(tmp_path).encode()) == 0
+        imgs = []
+        for expect in (0, 1):
+            m = HipTrace()
+            m.Startup(sc)
+            assert m.bvh_info()["from_cache"] == expect
+            m.render(0, 8)
+            imgs.append(m.resolve()[0])
+            m.Shutdown()
+        assert np.array_equal(imgs[0], imgs[1])
+    finally:
+        lib.trh_set_bvh_cache_dir(None)

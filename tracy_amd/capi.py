@@ -53,7 +53,7 @@ class trh_stats(C.Structure):
 class trh_bvh_info(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("tri_count", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
                 ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("sah_cost", C.c_double), ("build_ms", C.c_double),
-                ("fp16_inflation", C.c_double), ("builder", C.c_uint32), ("reserved", C.c_uint32), ("device_build_ms", C.c_double)]
+                ("fp16_inflation", C.c_double), ("builder", C.c_uint32), ("from_cache", C.c_uint32), ("device_build_ms", C.c_double)]
 
 
 class tsc_camera(C.Structure):
@@ -113,6 +113,7 @@ HIP_SYMBOLS = {
     "trh_bvh_build_host": (C.c_int, [C.POINTER(trh_scene_desc), C.POINTER(trh_bvh_info), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "trh_bvh_build_device": (C.c_int, [C.c_void_p, C.POINTER(trh_scene_desc), C.POINTER(trh_bvh_info), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "trh_set_builder": (C.c_int, [C.c_void_p, C.c_int]),
+    "trh_set_bvh_cache_dir": (C.c_int, [C.c_char_p]),
     "trh_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(trh_bvh_info)]),
 }
 

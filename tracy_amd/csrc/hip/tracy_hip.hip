@@ -365,6 +365,7 @@ __global__ void k_present(const float4* __restrict__ accum, uint32_t* __restrict
 namespace {
 
 thread_local std::string g_err;
+std::string g_bvh_cache_dir = [] { const char* e = getenv("TRH_BVH_CACHE"); return std::string(e ? e : ""); }();   // trh_set_bvh_cache_dir
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -872,7 +873,8 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
             fprintf(stderr, "trh_scene_upload: %s; using the host builder\n", why.c_str());
         }
     }
-    if (!built_on_device) bvh::build(tris, r);
+    bool from_cache = false;
+    if (!built_on_device) bvh::build_cached(tris, r, g_bvh_cache_dir, &from_cache);
     const auto t1 = std::chrono::steady_clock::now();
     if (r.max_depth > (uint32_t)TRH_STACK_SIZE) return fail(TRH_ERR_LIMIT, "trh_scene_upload: BVH deeper than the traversal stack");
 
@@ -1017,7 +1019,7 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     c->bvh.fp16_inflation = r.fp16_inflation;
     c->bvh.tri_bytes = (uint64_t)nprim * 48u;
     c->bvh.builder = built_on_device ? TRH_BUILDER_DEVICE_LBVH : TRH_BUILDER_HOST_SAH;
-    c->bvh.reserved = 0;
+    c->bvh.from_cache = from_cache ? 1u : 0u;
     c->bvh.device_build_ms = built_on_device ? dev_bvh.device_ms : 0.0;
     c->bvh.sah_cost = r.sah_cost;
     c->bvh.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -1031,7 +1033,8 @@ int trh_bvh_build_host(const trh_scene_desc* d, trh_bvh_info* info_out, uint64_t
     if (int frc = flatten_triangles(d, tris, any_normal_map)) return frc;
     const auto t0 = std::chrono::steady_clock::now();
     bvh::Result r;
-    bvh::build(tris, r);
+    bool from_cache = false;
+    bvh::build_cached(tris, r, g_bvh_cache_dir, &from_cache);
     const auto t1 = std::chrono::steady_clock::now();
     std::string why;
     *violations_out = bvh::validate(tris, r, why, hash_out);
@@ -1048,7 +1051,7 @@ int trh_bvh_build_host(const trh_scene_desc* d, trh_bvh_info* info_out, uint64_t
         info_out->build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         info_out->fp16_inflation = r.fp16_inflation;
         info_out->builder = TRH_BUILDER_HOST_SAH;
-        info_out->reserved = 0;
+        info_out->from_cache = from_cache ? 1u : 0u;
         info_out->device_build_ms = 0.0;
     }
     return TRH_OK;
@@ -1086,9 +1089,14 @@ int trh_bvh_build_device(trh_context* c, const trh_scene_desc* d, trh_bvh_info* 
         info_out->build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         info_out->fp16_inflation = r.fp16_inflation;
         info_out->builder = TRH_BUILDER_DEVICE_LBVH;
-        info_out->reserved = 0;
+        info_out->from_cache = 0;
         info_out->device_build_ms = device_ms;
     }
+    return TRH_OK;
+}
+
+int trh_set_bvh_cache_dir(const char* directory) {
+    g_bvh_cache_dir = directory ? directory : "";
     return TRH_OK;
 }
 

@@ -420,6 +420,117 @@ void build(const std::vector<InputTriangle>& tris, Result& out) {
                 std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
 }
 
+namespace {
+
+uint64_t fnv1a(const void* p, size_t bytes, uint64_t h = 1469598103934665603ull) {
+    const uint8_t* b = (const uint8_t*)p;
+    for (size_t i = 0; i < bytes; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+struct CacheHeader {
+    char magic[8];            // "TRHBVH1\0"
+    uint64_t key;             // hash of the input triangles + builder constants
+    uint64_t n_nodes_f32, n_nodes16, n_tris_f32, n_prims;   // element counts of the four arrays
+    float frame_center[3];
+    float frame_scale;
+    double fp16_inflation, sah_cost;
+    uint32_t max_depth, max_leaf;
+    uint64_t checksum;        // hash of the four arrays
+};
+static_assert(sizeof(CacheHeader) == 96, "cache header layout");
+constexpr char kCacheMagic[8] = {'T', 'R', 'H', 'B', 'V', 'H', '1', 0};
+
+uint64_t cache_key(const std::vector<InputTriangle>& tris) {
+    uint64_t h = fnv1a(tris.data(), tris.size() * sizeof(InputTriangle));
+    const float consts[4] = {kCostTraverse, kCostIntersect, (float)kSahBins, (float)kMaxLeafSize};
+    h = fnv1a(consts, sizeof(consts), h);
+    const uint64_t n = tris.size();
+    return fnv1a(&n, sizeof(n), h);
+}
+uint64_t arrays_checksum(const Result& r) {
+    uint64_t h = fnv1a(r.nodes.data(), r.nodes.size() * 4);
+    h = fnv1a(r.nodes16.data(), r.nodes16.size() * 4, h);
+    h = fnv1a(r.tris.data(), r.tris.size() * 4, h);
+    return fnv1a(r.prim_index.data(), r.prim_index.size() * 4, h);
+}
+
+bool cache_load(const std::string& path, uint64_t key, size_t n_tris, Result& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    CacheHeader h{};
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, kCacheMagic, 8) == 0 && h.key == key;
+    // sizes must be what a tree over n_tris triangles can have, before anything is allocated from them
+    ok = ok && h.n_prims == n_tris && h.n_tris_f32 == (uint64_t)n_tris * 12 && h.n_nodes_f32 % 16 == 0 && h.n_nodes16 * 2 == h.n_nodes_f32 &&
+         h.n_nodes_f32 / 16 >= 1 && h.n_nodes_f32 / 16 <= std::max<uint64_t>(n_tris, 1) && h.max_depth <= (uint32_t)kMaxDepth;
+    if (ok) {
+        out = Result{};
+        out.nodes.resize(h.n_nodes_f32);
+        out.nodes16.resize(h.n_nodes16);
+        out.tris.resize(h.n_tris_f32);
+        out.prim_index.resize(h.n_prims);
+        ok = fread(out.nodes.data(), 4, out.nodes.size(), f) == out.nodes.size() && fread(out.nodes16.data(), 4, out.nodes16.size(), f) == out.nodes16.size() &&
+             fread(out.tris.data(), 4, out.tris.size(), f) == out.tris.size() && fread(out.prim_index.data(), 4, out.prim_index.size(), f) == out.prim_index.size() &&
+             fgetc(f) == EOF && arrays_checksum(out) == h.checksum;
+        memcpy(out.frame_center, h.frame_center, sizeof(out.frame_center));
+        out.frame_scale = h.frame_scale;
+        out.fp16_inflation = h.fp16_inflation;
+        out.sah_cost = h.sah_cost;
+        out.max_depth = h.max_depth;
+        out.max_leaf = h.max_leaf;
+    }
+    fclose(f);
+    return ok;
+}
+
+void cache_store(const std::string& path, uint64_t key, const Result& r) {
+    CacheHeader h{};
+    memcpy(h.magic, kCacheMagic, 8);
+    h.key = key;
+    h.n_nodes_f32 = r.nodes.size();
+    h.n_nodes16 = r.nodes16.size();
+    h.n_tris_f32 = r.tris.size();
+    h.n_prims = r.prim_index.size();
+    memcpy(h.frame_center, r.frame_center, sizeof(h.frame_center));
+    h.frame_scale = r.frame_scale;
+    h.fp16_inflation = r.fp16_inflation;
+    h.sah_cost = r.sah_cost;
+    h.max_depth = r.max_depth;
+    h.max_leaf = r.max_leaf;
+    h.checksum = arrays_checksum(r);
+    const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;   // an unwritable cache directory is not an error: the tree was built
+    const bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(r.nodes.data(), 4, r.nodes.size(), f) == r.nodes.size() &&
+                    fwrite(r.nodes16.data(), 4, r.nodes16.size(), f) == r.nodes16.size() && fwrite(r.tris.data(), 4, r.tris.size(), f) == r.tris.size() &&
+                    fwrite(r.prim_index.data(), 4, r.prim_index.size(), f) == r.prim_index.size();
+    const bool closed = fclose(f) == 0;
+    if (!ok || !closed || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+}
+
+}  // namespace
+
+void build_cached(const std::vector<InputTriangle>& tris, Result& out, const std::string& dir, bool* from_cache_out) {
+    if (from_cache_out) *from_cache_out = false;
+    if (dir.empty()) { build(tris, out); return; }
+    if (const char* e = getenv("TRH_SAH_CT")) { const float v = (float)atof(e); if (v > 0.f) kCostTraverse = v; }   // part of the key
+    const uint64_t key = cache_key(tris);
+    char name[40];
+    snprintf(name, sizeof(name), "/%016llx.trhbvh", (unsigned long long)key);
+    const std::string path = dir + name;
+    if (cache_load(path, key, tris.size(), out)) {
+        // the checksum guards against a damaged file, not against a wrong one: links and leaf ranges go to the GPU
+        // unchecked by the kernels, so a loaded tree passes the same structural check as the tests' before it is used
+        std::string why;
+        if (validate(tris, out, why, nullptr) == 0) {
+            if (from_cache_out) *from_cache_out = true;
+            return;
+        }
+    }
+    build(tris, out);
+    cache_store(path, key, out);
+}
+
 uint64_t validate(const std::vector<InputTriangle>& tris, const Result& r, std::string& first, uint64_t* hash_out) {
     uint64_t bad = 0;
     auto fail = [&](const std::string& what) { if (bad++ == 0) first = what; };

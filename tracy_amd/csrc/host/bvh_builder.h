@@ -60,6 +60,14 @@ struct Result {
 
 void build(const std::vector<InputTriangle>& tris, Result& out);
 
+// On-disk cache of build results. build_cached() looks in `dir` for a file named after the
+// FNV-1a hash of the input triangles (and of the builder's constants and file-format version), checks its header,
+// sizes and a checksum of the arrays, and returns its contents; on a miss or any mismatch it builds, then writes the
+// file (to a temporary name, then rename: readers never see a partial file). from_cache_out tells which happened.
+// An empty dir means build(). The file is this builder's own format ("TRHBVH1\0", little endian, arrays as they are
+// in Result); a cache written by another version of the builder is ignored, not migrated.
+void build_cached(const std::vector<InputTriangle>& tris, Result& out, const std::string& dir, bool* from_cache_out);
+
 // Structural self-check of a build result (host only, used by trh_bvh_build_host and the CPU tests):
 // every triangle in exactly one leaf, every leaf box contains its triangles' vertices, every fp16 box
 // contains the fp32 box it was rounded from, depth / leaf size / link encoding within the documented
