@@ -613,3 +613,52 @@ def test_upload_from_the_bvh_cache_renders_the_same(scene_loader, tmp_path):
         assert np.array_equal(imgs[0], imgs[1])
     finally:
         lib.trh_set_bvh_cache_dir(None)
+
+
+def test_textured_spheres_with_the_earth_map(tmp_path, oracle_mod):
+    """data/earth.jpg ships with the reference but none of its scenes uses it: a scene of our own puts it on a
+    tessellated sphere as base colour (sRGB) and as emissive map of a second one -- sphere uv mapping
+    (scene.cpp:55-131), JPEG decode, the sRGB flag and Texture::GetPixel on procedural meshes, against the oracle."""
+    from tracy_amd import HipTrace
+    sc = _scene_from_text(tmp_path, """SCN Earth
+OUT 160 90
+CAM (0, 0.4, 3.2) (0, 0, 0) (0, 1, 0) 40
+MTL Light (1,1,1) 0 0 0 6
+MTL Earth (1,1,1) 0.6 0
+MTL Glow (1,1,1) 1 0 0 2
+MTL Floor (0.5,0.5,0.5) 0.9 0
+TEX Earth B data/earth.jpg SRGB
+TEX Glow E data/earth.jpg
+SKY (0.02,0.02,0.03)
+OBJ S (2.5, 4, 2) 1.2 Light
+OBJ S (-0.7, 0, 0) 0.8 Earth
+OBJ S (1.0, -0.2, 0.3) 0.5 Glow
+OBJ B (-6, -1.0, -6) (6, -0.8, 6) Floor
+""", "earth.scn")
+    assert len(sc.synthetic_textures) == 0
+    ref = oracle_mod.CpuRef(sc)
+    mod = HipTrace()
+    mod.Startup(sc)
+    try:
+        ids, t, uv = mod.primary_hits()
+        rids, rt, ruv = ref.primary_hits()
+        assert (ids == rids).mean() >= 0.9999
+        same = (ids == rids) & (ids != MISS)
+        assert np.array_equal(t[same], rt[same]) and np.array_equal(uv[same], ruv[same])
+        for view in (1, 5):                      # base colour and emissive: the texels themselves
+            mod.set_debug_view(view, sc.view3x3())
+            ref.set_debug_view(view, sc.view3x3())
+            a, b = mod.sample_radiance(0), ref.sample_radiance(0)
+            assert np.isclose(a[..., :3], b[..., :3], rtol=2e-6, atol=1e-7).all(axis=-1).mean() >= 0.999
+            assert len(np.unique(a[..., :3].reshape(-1, 3), axis=0)) > 200   # the map really varies over the sphere
+        mod.set_debug_view(0)
+        ref.set_debug_view(0)
+        for s in (0, 4):
+            a, b = mod.sample_radiance(s), ref.sample_radiance(s)
+            ok = np.isclose(a[..., :3], b[..., :3], rtol=1e-4, atol=1e-5).all(axis=-1) & (a[..., 3] == b[..., 3])
+            assert ok.mean() >= 0.995
+        mod.render(0, 16)
+        ref.render(0, 16)
+        assert psnr(mod.resolve()[0][..., :3], ref.output()) >= 40.0
+    finally:
+        mod.Shutdown()
