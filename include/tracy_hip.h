@@ -242,7 +242,8 @@ int trh_get_stats(trh_context* ctx, trh_stats* out, int reset);
  * out[0..4] = wave-level inner-node iterations, wave-level triangle-loop iterations, wave-level
  * shade calls, wave-level generate calls, lane-level generate calls; out[5..9] = shader-clock cycles
  * the waves spent in inner steps, triangle steps, shade, refill/generate and in the kernel altogether;
- * out[10] = lifetime of the longest-lived wave, out[11] = number of waves. Lane utilisation of a
+ * out[10] = lifetime of the longest-lived wave, out[11] = number of waves, out[12..15] = earliest wave start,
+ * latest wave end, sum of the wave starts, sum of the wave ends (device-wide 100 MHz clock). Lane utilisation of a
  * phase = lane-level count / (64 * wave-level count), e.g. (box_tests/2) / (64*out[0]). */
 int trh_get_debug_counters(trh_context* ctx, uint64_t* out, uint32_t n);
 

@@ -21,6 +21,10 @@ for scene in sys.argv[1:] or ["dragon"]:
             k = d["cycles_kernel"]
             if d.get("waves"):
                 print(f"   load balance: mean wave lifetime / longest = {k / d['waves'] / max(1, d['cycles_longest_wave']):.3f} ({d['waves']} waves)")
+            if d.get("waves") and d.get("t_last_end"):
+                w, span = d["waves"], d["t_last_end"] - d["t_first_start"]
+                print(f"   launch span {span} ticks; mean wave start {(d['t_sum_start'] / w - d['t_first_start']) / span:.4f} of the span after the first, "
+                      f"mean wave end {(d['t_last_end'] - d['t_sum_end'] / w) / span:.4f} of the span before the last")
             rest = k - d["cycles_inner"] - d["cycles_leaf"] - d["cycles_shade"] - d["cycles_refill"]
             print(f"   wave time split: inner {d['cycles_inner']/k:.3f} leaf {d['cycles_leaf']/k:.3f} shade {d['cycles_shade']/k:.3f} refill+generate {d['cycles_refill']/k:.3f} votes/tile bookkeeping {rest/k:.3f}")
         mod.Shutdown()

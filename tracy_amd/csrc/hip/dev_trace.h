@@ -73,6 +73,7 @@ struct Counters {
     uint32_t rays, box_tests, tri_tests, hits, tex_fetches;
     uint32_t w_inner, w_leaf, w_shade, w_gen, l_gen;   // instrumented kernel only
     unsigned long long cyc[5];                         // instrumented kernel only: wave cycles per phase (see DevCounters)
+    unsigned long long t_start;                        // instrumented kernel only: wave start on the device-wide clock
 };
 // true for exactly one of the currently active lanes (wave-level event counting)
 DEVFN bool first_active_lane() {

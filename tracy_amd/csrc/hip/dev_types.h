@@ -73,4 +73,5 @@ struct DevCounters {
     unsigned long long phase_cycles[5];
     unsigned long long max_wave_cycles;   // instrumented kernel only: the longest-lived wave (load balance = mean / max)
     unsigned long long waves;             // instrumented kernel only: waves that reported
+    unsigned long long min_start, max_end, sum_start, sum_end;   // instrumented kernel only: wave start / end times (device-wide 100 MHz clock)
 };

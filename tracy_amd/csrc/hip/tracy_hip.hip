@@ -65,6 +65,12 @@ DEVFN void flush_counters(const Counters& c, DevCounters* g) {
             for (int k = 0; k < 5; ++k) atomicAdd(&g->phase_cycles[k], c.cyc[k]);
             atomicMax(&g->max_wave_cycles, c.cyc[4]);
             atomicAdd(&g->waves, 1ull);
+            // device-wide constant-rate clock (the shader clock of c.cyc[] is per XCD and not comparable across waves)
+            const unsigned long long t_end = wall_clock64(), t_start = c.t_start;
+            atomicMax(&g->min_start, ~t_start);   // the counters start at zero: keep the maximum of the complement
+            atomicMax(&g->max_end, t_end);
+            atomicAdd(&g->sum_start, t_start);
+            atomicAdd(&g->sum_end, t_end);
         }
     }
 }
@@ -162,6 +168,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
     const uint32_t total = P * rp.spp_count;   // items per tile
     Counters cnt = {};
     const unsigned long long t_kernel = STATS ? __builtin_readcyclecounter() : 0ull;
+    if (STATS) cnt.t_start = wall_clock64();
 
     for (;;) {
         uint32_t tile = 0;
@@ -1271,9 +1278,10 @@ int trh_get_debug_counters(trh_context* c, uint64_t* out, uint32_t n) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     DevCounters h{};
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
-    const uint64_t v[12] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen,
-                            h.phase_cycles[0], h.phase_cycles[1], h.phase_cycles[2], h.phase_cycles[3], h.phase_cycles[4], h.max_wave_cycles, h.waves};
-    for (uint32_t i = 0; i < n; ++i) out[i] = i < 12 ? v[i] : 0;
+    const uint64_t v[16] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen,
+                            h.phase_cycles[0], h.phase_cycles[1], h.phase_cycles[2], h.phase_cycles[3], h.phase_cycles[4], h.max_wave_cycles, h.waves,
+                            ~h.min_start, h.max_end, h.sum_start, h.sum_end};
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 16 ? v[i] : 0;
     return TRH_OK;
 }
 
