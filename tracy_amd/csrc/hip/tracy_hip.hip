@@ -221,8 +221,10 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
                     const uint32_t item = next + rank;
                     if (item < total) {
-                        pix = item & (P - 1u);
-                        const uint32_t sample = rp.spp_begin + (item >> P_log2);
+                        // items run sample-major: the 64 lanes of a wave hold samples of one or two pixels, so their camera
+                        // rays walk the same nodes (-5 % dragon, -6 % spheres against pixel-major order)
+                        pix = item / rp.spp_count;
+                        const uint32_t sample = rp.spp_begin + (item - pix * rp.spp_count);
                         const int px = tile_x0 + (int)(pix & ((1u << rp.tile_w_log2) - 1u));
                         const int py = tile_y0 + (int)(pix >> rp.tile_w_log2);
                         if (px < sc.width && py < sc.height) {
