@@ -253,6 +253,9 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             // Lane state is readable from tv.node alone: >= 0 inner record, < -1 leaf, == -1 nothing to
             // traverse (finished, or no path), so each census is one v_cmp + s_bcnt1.
             const uint32_t nP = (uint32_t)__popcll(__ballot(has_path));   // constant during the traversal phase
+            // issue priority to the waves that are traversing (memory-bound steps: get their loads out first), over
+            // the waves in the compute-heavy shade / generate phase: -1 % (the other way round: +2 %)
+            __builtin_amdgcn_s_setprio(3);
             for (;;) {
                 const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
                 const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
@@ -268,6 +271,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                     if (STATS) cnt.cyc[1] += __builtin_readcyclecounter() - t_step;
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         // ---- flush the tile: plain read-modify-write, the tile belongs to this wave
         __builtin_amdgcn_wave_barrier();
