@@ -59,6 +59,7 @@ struct RenderParams {
     uint32_t stack_entries;   // LDS stack rows per lane (BVH depth + the sentinel row)
     uint32_t refill_thresh;   // lanes waiting for shade/refill that end a traversal phase
     uint32_t sched_beta4;     // inner step is chosen when 4*n_inner >= sched_beta4*n_leaf (0 = while-while)
+    uint32_t acc_copies;          // LDS accumulator copies per wave (1, 2, 4, 8)
     const uint32_t* tile_order;   // NULL: raster order; else the order the tile counter indexes (tile_order.h)
     uint32_t* tile_cost;          // NULL, or per-tile shader-clock ticks of this launch (input of the next launch's order)
 };

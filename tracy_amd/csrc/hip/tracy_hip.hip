@@ -163,7 +163,13 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
     const int lane = threadIdx.x & 63;
     const uint32_t P_log2 = rp.tile_w_log2 + rp.tile_h_log2;
     const uint32_t P = 1u << P_log2;
-    float* wacc = reinterpret_cast<float*>(s_dyn + rp.stack_entries * TRH_BLOCK) + (threadIdx.x >> 6) * (P * 3);
+    // Tile accumulators: rp.acc_copies (1, 2, 4 or 8) copies per wave, a lane adds into copy `lane mod copies`. The lanes of
+    // a wave hold samples of the same one or two pixels, so with one copy their ds_add_f32 would all hit the same three
+    // addresses and serialise (measured: 7 % of the launch). The copy stride is odd, so the copies of a pixel lie in
+    // different LDS banks.
+    const uint32_t acc_stride = P * 3u + 1u;
+    float* wacc = reinterpret_cast<float*>(s_dyn + rp.stack_entries * TRH_BLOCK) + (threadIdx.x >> 6) * (acc_stride * rp.acc_copies);
+    float* const lane_acc = wacc + ((uint32_t)lane & (rp.acc_copies - 1u)) * acc_stride;
     const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
     const uint32_t total = P * rp.spp_count;   // items per tile
     Counters cnt = {};
@@ -179,7 +185,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
         const unsigned long long t_tile = rp.tile_cost ? __builtin_readcyclecounter() : 0ull;
         const int tile_x0 = (int)((tile % rp.tiles_x) << rp.tile_w_log2);
         const int tile_y0 = (int)((tile / rp.tiles_x) << rp.tile_h_log2);
-        for (uint32_t i = lane; i < P * 3; i += 64) wacc[i] = 0.f;
+        for (uint32_t i = lane; i < acc_stride * rp.acc_copies; i += 64) wacc[i] = 0.f;
         __builtin_amdgcn_wave_barrier();
 
         uint32_t next = 0;          // wave-uniform: next unassigned item of this tile
@@ -205,9 +211,12 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                 if (cont) {
                     trav_begin(sc, tv, ps.o, ps.d, stack);
                 } else {
-                    __hip_atomic_fetch_add(&wacc[pix * 3 + 0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&wacc[pix * 3 + 1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&wacc[pix * 3 + 2], ps.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // (most paths of an emitter-lit scene under a black sky carry no light at all: x + 0 is x, skip the add)
+                    if (ps.radiance.x != 0.f || ps.radiance.y != 0.f || ps.radiance.z != 0.f) {
+                        __hip_atomic_fetch_add(&lane_acc[pix * 3 + 0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&lane_acc[pix * 3 + 1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&lane_acc[pix * 3 + 2], ps.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     has_path = false;
                 }
             }
@@ -281,7 +290,13 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             if (px < sc.width && py < sc.height) {
                 const size_t p = (size_t)py * sc.width + px;
                 float4 a = accum[p];
-                a.x += wacc[i * 3 + 0]; a.y += wacc[i * 3 + 1]; a.z += wacc[i * 3 + 2]; a.w += (float)rp.spp_count;
+                float r = 0.f, g = 0.f, b = 0.f;
+                for (uint32_t k = 0; k < rp.acc_copies; ++k) {   // fixed order: run-to-run identical
+                    r += wacc[k * acc_stride + i * 3 + 0];
+                    g += wacc[k * acc_stride + i * 3 + 1];
+                    b += wacc[k * acc_stride + i * 3 + 2];
+                }
+                a.x += r; a.y += g; a.z += b; a.w += (float)rp.spp_count;
                 accum[p] = a;
             }
         }
@@ -552,7 +567,12 @@ int launch_megakernel_tiled(trh_context* c, RenderParams rp, uint32_t wl, uint32
         rp.tile_order = c->tile_order_valid ? c->tile_order : nullptr;
         rp.tile_cost = c->tile_cost;
     }
-    size_t lds = ((size_t)rp.stack_entries * TRH_BLOCK + (size_t)TRH_WAVES_PER_BLOCK * (3u << (wl + hl))) * 4;
+    // accumulator copies per wave (see the kernel): as many (<= 8, <= 3 KB per wave) as leave four workgroups per CU their LDS
+    const size_t stack_bytes = (size_t)rp.stack_entries * TRH_BLOCK * 4;
+    auto acc_bytes = [&](uint32_t copies) { return (size_t)TRH_WAVES_PER_BLOCK * ((3u << (wl + hl)) + 1u) * copies * 4; };
+    rp.acc_copies = 8;
+    while (rp.acc_copies > 1u && (acc_bytes(rp.acc_copies) > 4u * 3200u || (stack_bytes + acc_bytes(rp.acc_copies)) * 4u > 160u * 1024u)) rp.acc_copies >>= 1;
+    size_t lds = stack_bytes + acc_bytes(rp.acc_copies);
     lds += c->lds_pad;   // development knob: lowers occupancy to measure latency sensitivity
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS, N16>, TRH_BLOCK, lds));
