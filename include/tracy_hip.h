@@ -243,7 +243,8 @@ int trh_get_stats(trh_context* ctx, trh_stats* out, int reset);
  * shade calls, wave-level generate calls, lane-level generate calls; out[5..9] = shader-clock cycles
  * the waves spent in inner steps, triangle steps, shade, refill/generate and in the kernel altogether;
  * out[10] = lifetime of the longest-lived wave, out[11] = number of waves, out[12..15] = earliest wave start,
- * latest wave end, sum of the wave starts, sum of the wave ends (device-wide 100 MHz clock). Lane utilisation of a
+ * latest wave end, sum of the wave starts, sum of the wave ends (device-wide 100 MHz clock), out[16..18] = lanes
+ * standing on a leaf / waiting for shade / without a path, summed over the inner-step votes. Lane utilisation of a
  * phase = lane-level count / (64 * wave-level count), e.g. (box_tests/2) / (64*out[0]). */
 int trh_get_debug_counters(trh_context* ctx, uint64_t* out, uint32_t n);
 

@@ -25,6 +25,11 @@ for scene in sys.argv[1:] or ["dragon"]:
                 w, span = d["waves"], d["t_last_end"] - d["t_first_start"]
                 print(f"   launch span {span} ticks; mean wave start {(d['t_sum_start'] / w - d['t_first_start']) / span:.4f} of the span after the first, "
                       f"mean wave end {(d['t_last_end'] - d['t_sum_end'] / w) / span:.4f} of the span before the last")
+            if d.get("wave_inner_iters"):
+                # the vote runs TRH_INNER_REPEAT (3) inner steps; the idle census is taken once per vote
+                votes = max(1, d["idle_leaf_in_inner"] + d["idle_wait_in_inner"] + d["idle_none_in_inner"])
+                per = lambda x: x / (64.0 * max(1, d["wave_inner_iters"] / 3.0))
+                print(f"   lanes idle at an inner vote: on a leaf {per(d['idle_leaf_in_inner']):.3f}, waiting for shade {per(d['idle_wait_in_inner']):.3f}, no path {per(d['idle_none_in_inner']):.3f}")
             rest = k - d["cycles_inner"] - d["cycles_leaf"] - d["cycles_shade"] - d["cycles_refill"]
             print(f"   wave time split: inner {d['cycles_inner']/k:.3f} leaf {d['cycles_leaf']/k:.3f} shade {d['cycles_shade']/k:.3f} refill+generate {d['cycles_refill']/k:.3f} votes/tile bookkeeping {rest/k:.3f}")
         mod.Shutdown()

@@ -74,6 +74,7 @@ struct Counters {
     uint32_t w_inner, w_leaf, w_shade, w_gen, l_gen;   // instrumented kernel only
     unsigned long long cyc[5];                         // instrumented kernel only: wave cycles per phase (see DevCounters)
     unsigned long long t_start;                        // instrumented kernel only: wave start on the device-wide clock
+    uint32_t idle_leaf, idle_wait, idle_none;          // instrumented kernel only, wave-level (lane 0 counts): see DevCounters
 };
 // true for exactly one of the currently active lanes (wave-level event counting)
 DEVFN bool first_active_lane() {

@@ -74,5 +74,6 @@ struct DevCounters {
     unsigned long long phase_cycles[5];
     unsigned long long max_wave_cycles;   // instrumented kernel only: the longest-lived wave (load balance = mean / max)
     unsigned long long waves;             // instrumented kernel only: waves that reported
+    unsigned long long idle_leaf_in_inner, idle_wait_in_inner, idle_none_in_inner;   // instrumented kernel only: lanes standing on a leaf / waiting for shade / without a path, summed over inner steps
     unsigned long long min_start, max_end, sum_start, sum_end;   // instrumented kernel only: wave start / end times (device-wide 100 MHz clock)
 };

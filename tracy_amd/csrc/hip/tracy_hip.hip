@@ -64,6 +64,9 @@ DEVFN void flush_counters(const Counters& c, DevCounters* g) {
             atomicAdd(&g->lanes_gen, (unsigned long long)f);
             for (int k = 0; k < 5; ++k) atomicAdd(&g->phase_cycles[k], c.cyc[k]);
             atomicMax(&g->max_wave_cycles, c.cyc[4]);
+            atomicAdd(&g->idle_leaf_in_inner, (unsigned long long)c.idle_leaf);
+            atomicAdd(&g->idle_wait_in_inner, (unsigned long long)c.idle_wait);
+            atomicAdd(&g->idle_none_in_inner, (unsigned long long)c.idle_none);
             atomicAdd(&g->waves, 1ull);
             // device-wide constant-rate clock (the shader clock of c.cyc[] is per XCD and not comparable across waves)
             const unsigned long long t_end = wall_clock64(), t_start = c.t_start;
@@ -271,6 +274,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                 if ((nI | nL) == 0u || nP - nI - nL >= rp.refill_thresh) break;
                 const unsigned long long t_step = STATS ? __builtin_readcyclecounter() : 0ull;
                 if (nI != 0u && nI * 4u >= nL * rp.sched_beta4) {
+                    if (STATS && lane == 0) { cnt.idle_leaf += nL; cnt.idle_wait += nP - nI - nL; cnt.idle_none += 64u - nP; }
 #pragma unroll
                     for (int r = 0; r < TRH_INNER_REPEAT; ++r)
                         if (tv.node >= 0) trav_inner<STATS, N16>(sc, ps.o, tv, stack, cnt);
@@ -1304,10 +1308,10 @@ int trh_get_debug_counters(trh_context* c, uint64_t* out, uint32_t n) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     DevCounters h{};
     HIP_TRY(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
-    const uint64_t v[16] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen,
+    const uint64_t v[19] = {h.wave_inner_iters, h.wave_leaf_iters, h.wave_shade_calls, h.wave_gen_calls, h.lanes_gen,
                             h.phase_cycles[0], h.phase_cycles[1], h.phase_cycles[2], h.phase_cycles[3], h.phase_cycles[4], h.max_wave_cycles, h.waves,
-                            ~h.min_start, h.max_end, h.sum_start, h.sum_end};
-    for (uint32_t i = 0; i < n; ++i) out[i] = i < 16 ? v[i] : 0;
+                            ~h.min_start, h.max_end, h.sum_start, h.sum_end, h.idle_leaf_in_inner, h.idle_wait_in_inner, h.idle_none_in_inner};
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 19 ? v[i] : 0;
     return TRH_OK;
 }
 

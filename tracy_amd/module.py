@@ -154,11 +154,12 @@ class HipTrace:
 
     def debug_counters(self):
         """Wave-level iteration counts of the instrumented kernel (see trh_get_debug_counters)."""
-        out = (C.c_uint64 * 16)()
-        self._check(self._lib.trh_get_debug_counters(self._ctx, out, 16))
+        out = (C.c_uint64 * 19)()
+        self._check(self._lib.trh_get_debug_counters(self._ctx, out, 19))
         return dict(zip(["wave_inner_iters", "wave_leaf_iters", "wave_shade_calls", "wave_gen_calls", "lanes_gen",
                          "cycles_inner", "cycles_leaf", "cycles_shade", "cycles_refill", "cycles_kernel", "cycles_longest_wave", "waves",
-                         "t_first_start", "t_last_end", "t_sum_start", "t_sum_end"], list(out)))
+                         "t_first_start", "t_last_end", "t_sum_start", "t_sum_end",
+                         "idle_leaf_in_inner", "idle_wait_in_inner", "idle_none_in_inner"], list(out)))
 
     def bvh_build_device(self, scene):
         """trh_bvh_build_device: (info dict, layout hash, violations) of the device-side linear BVH of `scene`."""
