@@ -121,7 +121,12 @@ DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 d, float t, uint32_t id
     const float t_b = c_later ? t : hit.t;
     const uint32_t mb = c_later ? mc : mh;
     const float4 bmn = sc.mesh_aabb[mb * 2 + 0], bmx = sc.mesh_aabb[mb * 2 + 1];
-    const V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);   // Ray ctor (src/ray.h:18); rare path, not worth registers
+    // Ray ctor (src/ray.h:18). This branch is rare; the empty asm pins the three IEEE divisions here -- without it the
+    // compiler hoists them (d is loop-invariant) to the head of every traversal phase: 33 instructions for all lanes
+    // and three live registers through the hot loop.
+    float dx = d.x, dy = d.y, dz = d.z;
+    asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
+    const V3 inv = mk(1.f / dx, 1.f / dy, 1.f / dz);
     const float x0 = (bmn.x - o.x) * inv.x, x1 = (bmx.x - o.x) * inv.x;
     const float y0 = (bmn.y - o.y) * inv.y, y1 = (bmx.y - o.y) * inv.y;
     const float z0 = (bmn.z - o.z) * inv.z, z1 = (bmx.z - o.z) * inv.z;
