@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TRH_ABI_VERSION 1
+#define TRH_ABI_VERSION 2
 
 typedef enum trh_status {
     TRH_OK = 0,
@@ -212,6 +212,7 @@ int trh_resolve(trh_context* ctx, float* rgba_host, uint64_t* samples_out);
  * (cpu_details.cpp:201-243, bitmap.cpp:58-69) for the whole frame on the device:
  * mean = sum / count, colour * exposure, tone curve, srgb(), clamp(255.99 * c, 0, 255), u8
  * truncation, packed as 0x00RRGGBB (bytes B,G,R,0 -- the XImage/DIB layout of bitmap.cpp:28-39).
+ * The no-tonemap variant leaves the exposure out, like the reference's #else branch (cpu_details.cpp:236-238).
  * Output row 0 is the TOP row of the picture (the reference flips in SetPixel; it writes row
  * `height - y`, one past the end for y = 0 -- this call uses the evident intent height-1-y).
  * tonemap selects the reference's compile-time variants (CMakeLists.txt:92-103):
@@ -286,6 +287,50 @@ int trh_set_bvh_cache_dir(const char* directory);
  * the arrays back and runs the same structural self-check and hash on them. Leaves the context's resident
  * scene alone. Fails with TRH_ERR_LIMIT where trh_scene_upload would fall back to the host builder. */
 int trh_bvh_build_device(trh_context* ctx, const trh_scene_desc* scene, trh_bvh_info* info_out, uint64_t* hash_out, uint64_t* violations_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: one host thread drives the N GPUs of a node.
+ *
+ * The reference is one process with one host thread that calls Startup once and then
+ * OnEvent* / OnUpdate / OnRender per frame (src/win_raytracer.cpp:480, 494-517); it has no multi-device
+ * path of any kind. A group is that same call protocol over N devices: device g renders the sample indices
+ * [g*S/N, (g+1)*S/N) of every trh_group_render call of S samples (the scene is replicated, paths are
+ * independent), each into its own float4 sum buffer, and trh_group_resolve / trh_group_present_bgra8 run
+ * the path's one exchange step -- ncclReduce(sum, float, width*height*4, root = device 0) over xGMI inside
+ * ncclGroupStart/End, enqueued on the devices' render streams -- before the mean / tonemap on device 0.
+ * The per-device sums are left as they are, so rendering goes on after a resolve. The sample set of a call
+ * does not depend on N (the RNG is keyed by pixel, global sample index and seed); the image agrees with
+ * the one-device image to float summation order.
+ * A group of one device uses no RCCL and is the plain context, bit for bit (TRH_GROUP_FORCE_RCCL=1 runs the
+ * reduce anyway, for testing). RCCL (librccl.so.1) is loaded when the first group of >= 2 devices is made.
+ * Each function below is the trh_* call of the same name applied to every device; errors as there. */
+typedef struct trh_group trh_group;
+
+/* Startup, device half, for min(ngpus_requested, devices present) GPUs, devices 0..n-1 (ngpus_requested <= 0:
+ * all of them). Extends trh_init / TracyModule::Startup (src/module.h:35). */
+int trh_group_init(int ngpus_requested, int* ngpus_out, trh_group** group_out);
+int trh_group_shutdown(trh_group* group);                                   /* TracyModule::Shutdown (src/module.h:38) */
+int trh_group_size(const trh_group* group);
+/* the single-device context of member `index` (0 = root), e.g. for trh_get_bvh_info or the parity probes */
+int trh_group_context(trh_group* group, int index, trh_context** ctx_out);
+int trh_group_set_builder(trh_group* group, int builder /* trh_builder */);
+/* trh_scene_upload on every device; the host-side BVH build runs once and its arrays are copied to each GPU */
+int trh_group_scene_upload(trh_group* group, const trh_scene_desc* scene);
+int trh_group_set_camera(trh_group* group, const float eye[3], const float inv_view_proj[16]);
+int trh_group_set_debug_view(trh_group* group, int view /* trh_debug_view */, const float view3x3[9]);
+int trh_group_reset_accumulation(trh_group* group);                         /* eCameraCut (cpu_trace.cpp:72-82) */
+/* THE HOT CALL on N devices (CpuTrace::OnUpdate, cpu_trace.cpp:33-70). Asynchronous: enqueues one trh_render
+ * per device and returns. A call of fewer samples than devices leaves some devices idle. */
+int trh_group_render(trh_group* group, uint32_t spp_begin, uint32_t spp_count, uint64_t seed);
+int trh_group_synchronize(trh_group* group);
+/* exchange step + trh_resolve on device 0; samples_out = samples per pixel over all devices since the last reset */
+int trh_group_resolve(trh_group* group, float* rgba_host, uint64_t* samples_out);
+/* exchange step + trh_present_bgra8 on device 0 (TracyModule::OnRender, cpu_details.cpp:201-243) */
+int trh_group_present_bgra8(trh_group* group, int tonemap /* trh_tonemap */, float exposure, uint32_t* bgra_host);
+/* counters summed over the devices; kernel_ms / launches are those of the slowest device (they run side by side) */
+int trh_group_get_stats(trh_group* group, trh_stats* out, int reset);
+/* the sample split used by trh_group_render (pure host arithmetic, no device needed): the range of device g of ngpus */
+void trh_split_samples(uint32_t spp_begin, uint32_t spp_count, int ngpus, int g, uint32_t* begin_out, uint32_t* count_out);
 
 #ifdef __cplusplus
 }

@@ -837,8 +837,8 @@ void oref_tonemap_bgra8(const float* rgb, uint32_t w, uint32_t h, int mode, floa
             const float* p = rgb + ((size_t)y * w + x) * 3;
             uint32_t b[3];
             for (int k = 0; k < 3; ++k) {
-                float v = p[k] * exposure;
-                if (mode != 0) v = srgb(curve(v));
+                float v = p[k];
+                if (mode != 0) v = srgb(curve(v * exposure));   // the no-tonemap build does not apply kExposure (cpu_details.cpp:236-238)
                 v = std::min(std::max(255.99f * v, 0.f), 255.f);
                 b[k] = (uint32_t)(uint8_t)v;
             }

@@ -22,7 +22,7 @@ def test_hip_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(capi.HIP_SYMBOLS) == names
-    assert lib.trh_abi_version() == 1
+    assert lib.trh_abi_version() == 2
 
 
 def test_scene_library_exports_every_declared_symbol():

@@ -31,9 +31,11 @@ def test_oracle_tonemap_known_values():
     aces = (1.0 * (2.51 + 0.03)) / (1.0 * (2.43 + 0.59) + 0.14)
     out_a = tonemap_bgra8(np.full((1, 1, 3), x, np.float32), mode=3)
     assert (out_a[0, 0] & 255) == int(255.99 * (aces ** 0.41666 * 1.055 - 0.055))
-    # no tonemap: clamp(255.99 * c)
+    # no tonemap: clamp(255.99 * c), WITHOUT the exposure (the #else branch of cpu_details.cpp:236-238)
     out_n = tonemap_bgra8(np.full((1, 1, 3), 0.25, np.float32), mode=0, exposure=2.0)
-    assert (out_n[0, 0] & 255) == int(255.99 * 0.5)
+    assert (out_n[0, 0] & 255) == int(255.99 * 0.25)
+    out_s = tonemap_bgra8(np.full((1, 1, 3), 0.25, np.float32), mode=1, exposure=2.0)
+    assert (out_s[0, 0] & 255) == int(255.99 * (0.5 ** 0.41666 * 1.055 - 0.055))
 
 
 @pytest.mark.gpu

@@ -5,4 +5,4 @@ Holds only what the per-sample path-tracing hot path needs: the HIP kernels + C 
 thin ctypes mirrors of the reference's Scene / TracyModule interfaces.
 """
 from .scene import Scene, SceneError  # noqa: F401
-from .module import HipTrace, HipError  # noqa: F401
+from .module import HipTrace, HipTraceGroup, HipError, split_samples  # noqa: F401

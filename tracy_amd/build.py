@@ -59,8 +59,8 @@ def build_hip(force=False, extra=()):
         extra = list(extra) + os.environ.get("TRH_HIPCC_EXTRA", "").split()
         _run([HIPCC, *HIP_FLAGS, *extra, "-shared",
               os.path.join(HERE, "csrc", "hip", "tracy_hip.hip"), os.path.join(HERE, "csrc", "hip", "lbvh_build.hip"),
-              os.path.join(HERE, "csrc", "hip", "tile_order.hip"),
-              os.path.join(HERE, "csrc", "host", "bvh_builder.cpp"), "-o", out])
+              os.path.join(HERE, "csrc", "hip", "tile_order.hip"), os.path.join(HERE, "csrc", "hip", "tracy_group.hip"),
+              os.path.join(HERE, "csrc", "host", "bvh_builder.cpp"), "-ldl", "-o", out])
     return out
 
 

@@ -115,6 +115,21 @@ HIP_SYMBOLS = {
     "trh_set_builder": (C.c_int, [C.c_void_p, C.c_int]),
     "trh_set_bvh_cache_dir": (C.c_int, [C.c_char_p]),
     "trh_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(trh_bvh_info)]),
+    "trh_group_init": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "trh_group_shutdown": (C.c_int, [C.c_void_p]),
+    "trh_group_size": (C.c_int, [C.c_void_p]),
+    "trh_group_context": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "trh_group_set_builder": (C.c_int, [C.c_void_p, C.c_int]),
+    "trh_group_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(trh_scene_desc)]),
+    "trh_group_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "trh_group_set_debug_view": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "trh_group_reset_accumulation": (C.c_int, [C.c_void_p]),
+    "trh_group_render": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "trh_group_synchronize": (C.c_int, [C.c_void_p]),
+    "trh_group_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "trh_group_present_bgra8": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "trh_group_get_stats": (C.c_int, [C.c_void_p, C.POINTER(trh_stats), C.c_int]),
+    "trh_split_samples": (None, [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
 

@@ -19,9 +19,11 @@
 #include "lbvh_build.h"
 #include "tile_order.h"
 #include "dev_trace.h"
+#include "ctx_internal.h"
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -376,7 +378,9 @@ __global__ void k_present(const float4* __restrict__ accum, uint32_t* __restrict
     const int x = (int)(p % (uint32_t)width), y = (int)(p / (uint32_t)width);
     const float4 a = accum[p];
     const float inv = a.w > 0.f ? 1.f / a.w : 0.f;
-    float c[3] = {a.x * inv * exposure, a.y * inv * exposure, a.z * inv * exposure};
+    // the reference's no-tonemap build returns the colour as it is, without kExposure (cpu_details.cpp:236-238)
+    const float ex = mode != TRH_TONEMAP_NONE ? exposure : 1.f;
+    float c[3] = {a.x * inv * ex, a.y * inv * ex, a.z * inv * ex};
     uint32_t b[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -422,6 +426,18 @@ uint32_t seed_hash_of(uint64_t seed) {
 
 }  // namespace
 
+// Scratch of one megakernel launch sequence: the tile counter the persistent waves pull from and the arrays of the
+// cost-ordered tile hand-out (tile_order.h). trh_render keeps one per context in hipMalloc'ed memory (the order is
+// reused by the next launch of the same tiling).
+struct TileState {
+    unsigned int* tile_counter = nullptr;
+    uint32_t *cost = nullptr, *order = nullptr, *keys = nullptr, *keys_sorted = nullptr, *iota = nullptr;
+    void* sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    uint32_t count = 0, shape = 0;   // the tiling the arrays belong to
+    bool order_valid = false;
+};
+
 struct trh_context {
     int builder = TRH_BUILDER_HOST_SAH;
     uint32_t debug_view = 0;
@@ -439,14 +455,9 @@ struct trh_context {
     float4* resolved = nullptr;
     uint32_t* bitmap = nullptr;       // BGRA8 picture of trh_present_bgra8
     DevCounters* counters = nullptr;
-    unsigned int* tile_counter = nullptr;
     // cost-ordered tile scheduling (tile_order.h); the arrays live until the next scene upload
     bool tile_feedback = true;
-    bool tile_order_valid = false;
-    uint32_t tile_count = 0, tile_shape = 0;   // the tiling the arrays below belong to
-    uint32_t *tile_cost = nullptr, *tile_order = nullptr, *tile_keys = nullptr, *tile_keys_sorted = nullptr, *tile_iota = nullptr;
-    void* tile_scratch = nullptr;
-    size_t tile_scratch_bytes = 0;
+    TileState ts;
     uint64_t samples = 0;        // since the last stats reset
     uint64_t accum_spp = 0;      // samples per pixel in the accumulation buffer
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // render launches not yet timed
@@ -457,6 +468,9 @@ struct trh_context {
     uint32_t refill_thresh = 40;   // swept 16..48 with the cost-ordered 2048-item tiles
     uint32_t sched_beta4 = 6;
     size_t lds_pad = 0;
+    // device buffer of the parity probes (trh_primary_hits / trh_sample_radiance), grown on demand, freed at shutdown
+    void* probe_buf = nullptr;
+    size_t probe_bytes = 0;
     // wavefront pipeline state (allocated on first use)
     WfBuffers wf{};
     std::vector<void*> wf_allocs;
@@ -488,11 +502,23 @@ int free_scene(trh_context* c) {
     c->accum_internal = nullptr;
     c->resolved = nullptr;
     c->bitmap = nullptr;
-    c->tile_cost = c->tile_order = c->tile_keys = c->tile_keys_sorted = c->tile_iota = nullptr;
-    c->tile_scratch = nullptr;
-    c->tile_count = 0;
-    c->tile_order_valid = false;
+    {
+        unsigned int* counter = c->ts.tile_counter;   // allocated by trh_init, lives as long as the context
+        c->ts = TileState{};
+        c->ts.tile_counter = counter;
+    }
     c->has_scene = false;
+    return TRH_OK;
+}
+
+int ensure_probe_buffer(trh_context* c, size_t bytes) {
+    if (c->probe_bytes >= bytes) return TRH_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->probe_buf);
+    c->probe_buf = nullptr;
+    c->probe_bytes = 0;
+    HIP_TRY(hipMalloc(&c->probe_buf, bytes));
+    c->probe_bytes = bytes;
     return TRH_OK;
 }
 
@@ -522,17 +548,18 @@ int launch_megakernel_simple(trh_context* c, RenderParams rp) {
     rp.tile_w_log2 = rp.tile_h_log2 = 3;
     rp.tiles_x = (uint32_t)(c->sc.width + 7) / 8;
     rp.tiles_y = (uint32_t)(c->sc.height + 7) / 8;
-    HIP_TRY(hipMemsetAsync(c->tile_counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((k_megakernel_simple<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), 0, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
+    HIP_TRY(hipMemsetAsync(c->ts.tile_counter, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL((k_megakernel_simple<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), 0, c->stream, c->sc, rp, c->accum, c->counters, c->ts.tile_counter);
     HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
 
-// (re)allocates the tile-order arrays for a tiling of ntiles tiles; a new tiling starts in raster order
+// (re)allocates the context's tile-order arrays for a tiling of ntiles tiles; a new tiling starts in raster order
 int ensure_tile_order(trh_context* c, uint32_t ntiles, uint32_t shape) {
-    if (c->tile_count == ntiles && c->tile_shape == shape && c->tile_cost) return TRH_OK;
+    TileState& ts = c->ts;
+    if (ts.count == ntiles && ts.shape == shape && ts.cost) return TRH_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    void** arrays[6] = {(void**)&c->tile_cost, (void**)&c->tile_order, (void**)&c->tile_keys, (void**)&c->tile_keys_sorted, (void**)&c->tile_iota, &c->tile_scratch};
+    void** arrays[6] = {(void**)&ts.cost, (void**)&ts.order, (void**)&ts.keys, (void**)&ts.keys_sorted, (void**)&ts.iota, &ts.sort_temp};
     for (void** a : arrays) {
         if (*a) {
             c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), *a), c->allocs.end());
@@ -540,24 +567,43 @@ int ensure_tile_order(trh_context* c, uint32_t ntiles, uint32_t shape) {
             *a = nullptr;
         }
     }
-    c->tile_order_valid = false;
-    c->tile_count = 0;
-    c->tile_scratch_bytes = tile_order::scratch_bytes(ntiles);
+    ts.order_valid = false;
+    ts.count = 0;
+    ts.sort_temp_bytes = tile_order::scratch_bytes(ntiles);
     for (int k = 0; k < 6; ++k) {
         void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, k < 5 ? (size_t)ntiles * sizeof(uint32_t) : std::max<size_t>(c->tile_scratch_bytes, 16)));
+        HIP_TRY(hipMalloc(&p, k < 5 ? (size_t)ntiles * sizeof(uint32_t) : std::max<size_t>(ts.sort_temp_bytes, 16)));
         c->allocs.push_back(p);
         *arrays[k] = p;
     }
-    HIP_TRY(hipMemsetAsync(c->tile_cost, 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
-    c->tile_count = ntiles;
-    c->tile_shape = shape;
+    HIP_TRY(hipMemsetAsync(ts.cost, 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
+    ts.count = ntiles;
+    ts.shape = shape;
     return TRH_OK;
 }
 
-// one launch of the megakernel with the tiling (wl, hl)
+// The tiling of a launch: tile = P pixels x spp items, P = 2x2 ... 16x16 pixels. Two wishes pull on P: a tile should hold
+// enough items for the wave-local scheduler to keep its lanes busy (best about 2048 = 32 per lane, no use below 512), and
+// the launch should have about 16 tiles per resident wave to balance. Measured on the dragon at 1080p (32400 tiles of 64
+// pixels = 7.9 per wave): 64 spp: 8x8 pixels 15.9 ms, 8x4 13.0, 4x4 13.6; 32 spp: 8x8 8.3, 8x4 7.1; 16 spp: 4.3 / 4.0;
+// 8 spp: 2.44 / 2.56; 1 spp: 16x16 pixels 1.01 ms, 16x8 0.84, 8x8 0.77.
+void choose_tiling(const trh_context* c, uint32_t spp_count, uint32_t& wl, uint32_t& hl, uint32_t& ntiles) {
+    const double pixels = (double)c->sc.width * (double)c->sc.height;
+    const double resident_waves = (double)c->num_cus * 16.0;
+    const double p_wish = std::min(2048.0 / (double)spp_count, pixels / (resident_waves * 16.0));
+    uint32_t p_log2 = 2;
+    while (p_log2 < 8u && (double)(2u << p_log2) <= p_wish * 1.4142135) ++p_log2;   // nearest power of two
+    // few samples: rather 512 items per tile than 16 tiles per wave, down to 4 tiles per wave
+    while (p_log2 < 8u && (uint64_t)(1u << p_log2) * spp_count < 512u && pixels / (double)(2u << p_log2) >= resident_waves * 4.0) ++p_log2;
+    wl = (p_log2 + 1u) / 2u;
+    hl = p_log2 / 2u;
+    ntiles = (((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl) * (((uint32_t)c->sc.height + (1u << hl) - 1u) >> hl);
+}
+
+// one launch of the megakernel with the tiling (wl, hl); `ts` holds the tile counter and, for an ordered launch, the
+// arrays of the cost order (already sized for this tiling)
 template <bool STATS, bool N16>
-int launch_megakernel_tiled(trh_context* c, RenderParams rp, uint32_t wl, uint32_t hl, bool ordered) {
+int launch_megakernel_tiled(trh_context* c, TileState& ts, RenderParams rp, uint32_t wl, uint32_t hl, bool ordered) {
     rp.tile_w_log2 = wl;
     rp.tile_h_log2 = hl;
     rp.tiles_x = ((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl;
@@ -566,10 +612,8 @@ int launch_megakernel_tiled(trh_context* c, RenderParams rp, uint32_t wl, uint32
     rp.refill_thresh = c->refill_thresh;
     rp.sched_beta4 = c->sched_beta4;
     if (ordered) {
-        const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
-        if (int orc = ensure_tile_order(c, ntiles, (wl << 8) | hl)) return orc;
-        rp.tile_order = c->tile_order_valid ? c->tile_order : nullptr;
-        rp.tile_cost = c->tile_cost;
+        rp.tile_order = ts.order_valid ? ts.order : nullptr;
+        rp.tile_cost = ts.cost;
     }
     // accumulator copies per wave (see the kernel): as many (<= 8, <= 3 KB per wave) as leave four workgroups per CU their LDS
     const size_t stack_bytes = (size_t)rp.stack_entries * TRH_BLOCK * 4;
@@ -582,49 +626,42 @@ int launch_megakernel_tiled(trh_context* c, RenderParams rp, uint32_t wl, uint32
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS, N16>, TRH_BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     const int grid = per_cu * c->num_cus;
-    HIP_TRY(hipMemsetAsync(c->tile_counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((k_megakernel<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, c->tile_counter);
+    HIP_TRY(hipMemsetAsync(ts.tile_counter, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL((k_megakernel<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, ts.tile_counter);
     HIP_TRY(hipGetLastError());
     if (ordered) {
-        const int e = tile_order::sort_by_cost(c->tile_cost, c->tile_order, c->tile_count, c->tile_keys, c->tile_keys_sorted, c->tile_iota, c->tile_scratch,
-                                               c->tile_scratch_bytes, c->stream);
+        const int e = tile_order::sort_by_cost(ts.cost, ts.order, ts.count, ts.keys, ts.keys_sorted, ts.iota, ts.sort_temp, ts.sort_temp_bytes, c->stream);
         if (e != 0) return fail(TRH_ERR_HIP, std::string("tile_order::sort_by_cost: ") + hipGetErrorString((hipError_t)e));
-        c->tile_order_valid = true;
+        ts.order_valid = true;
     }
     return TRH_OK;
 }
 
+// The launch sequence of one trh_render call on the tile state `ts` (whose arrays fit the tiling (wl, hl) if `ordered`).
+// Cost-ordered tiles (tile_order.h): a launch records what every tile cost, the next launch of the same tiling hands the
+// tiles out most expensive first. The first launch of a tiling has no costs yet: its first sample is traced as a launch of
+// its own, in raster order, and its tile costs order the rest (dragon, 64 spp on a fresh context: 14.5 ms instead of 21).
 template <bool STATS, bool N16>
-int launch_megakernel(trh_context* c, RenderParams rp) {
-    // tile = P pixels x spp items, P = 2x2 ... 16x16 pixels. Two wishes pull on P: a tile should hold enough items for
-    // the wave-local scheduler to keep its lanes busy (best about 2048 = 32 per lane, no use below 512), and the launch
-    // should have about 16 tiles per resident wave to balance. Measured on the dragon at 1080p (32400 tiles of 64
-    // pixels = 7.9 per wave): 64 spp: 8x8 pixels 15.9 ms, 8x4 13.0, 4x4 13.6; 32 spp: 8x8 8.3, 8x4 7.1; 16 spp: 4.3 / 4.0;
-    // 8 spp: 2.44 / 2.56; 1 spp: 16x16 pixels 1.01 ms, 16x8 0.84, 8x8 0.77.
-    const double pixels = (double)c->sc.width * (double)c->sc.height;
-    const double resident_waves = (double)c->num_cus * 16.0;
-    const double p_wish = std::min(2048.0 / (double)rp.spp_count, pixels / (resident_waves * 16.0));
-    uint32_t p_log2 = 2;
-    while (p_log2 < 8u && (double)(2u << p_log2) <= p_wish * 1.4142135) ++p_log2;   // nearest power of two
-    // few samples: rather 512 items per tile than 16 tiles per wave, down to 4 tiles per wave
-    while (p_log2 < 8u && (uint64_t)(1u << p_log2) * rp.spp_count < 512u && pixels / (double)(2u << p_log2) >= resident_waves * 4.0) ++p_log2;
-    const uint32_t wl = (p_log2 + 1u) / 2u, hl = p_log2 / 2u;
-    // cost-ordered tiles (tile_order.h): a launch records what every tile cost, the next launch of the same tiling
-    // hands the tiles out most expensive first. Launches of a few samples keep raster order: the re-sort would cost a
-    // noticeable part of a 1 ms launch.
-    const bool ordered = c->tile_feedback && rp.spp_count >= 8;
-    // The first launch of a tiling has no costs yet: its first sample is traced as a launch of its own, in raster
-    // order, and its tile costs order the rest (dragon, 64 spp on a fresh context: 14.5 ms instead of 21).
-    const bool have_order = c->tile_order_valid && c->tile_count == (((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl) * (((uint32_t)c->sc.height + (1u << hl) - 1u) >> hl) &&
-                            c->tile_shape == ((wl << 8) | hl);
-    if (ordered && !have_order && rp.spp_count >= 16) {
+int launch_megakernel_on(trh_context* c, TileState& ts, RenderParams rp, uint32_t wl, uint32_t hl, bool ordered) {
+    if (ordered && !ts.order_valid && rp.spp_count >= 16) {
         RenderParams probe = rp;
         probe.spp_count = 1;
-        if (int prc = launch_megakernel_tiled<STATS, N16>(c, probe, wl, hl, true)) return prc;
+        if (int prc = launch_megakernel_tiled<STATS, N16>(c, ts, probe, wl, hl, true)) return prc;
         rp.spp_begin += 1;
         rp.spp_count -= 1;
     }
-    return launch_megakernel_tiled<STATS, N16>(c, rp, wl, hl, ordered);
+    return launch_megakernel_tiled<STATS, N16>(c, ts, rp, wl, hl, ordered);
+}
+
+template <bool STATS, bool N16>
+int launch_megakernel(trh_context* c, RenderParams rp) {
+    uint32_t wl, hl, ntiles;
+    choose_tiling(c, rp.spp_count, wl, hl, ntiles);
+    // Launches of a few samples keep raster order: the re-sort would cost a noticeable part of a 1 ms launch.
+    const bool ordered = c->tile_feedback && rp.spp_count >= 8;
+    if (ordered)
+        if (int orc = ensure_tile_order(c, ntiles, (wl << 8) | hl)) return orc;   // a new tiling starts without an order
+    return launch_megakernel_on<STATS, N16>(c, c->ts, rp, wl, hl, ordered);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -743,6 +780,9 @@ int flatten_triangles(const trh_scene_desc* d, std::vector<bvh::InputTriangle>& 
                 if (li >= me.vertex_count) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: vertex index out of range");
                 const float* v = d->vertices + (size_t)(me.first_vertex + li) * TRH_VERTEX_FLOATS;
                 float* dst = k == 0 ? it.v0 : (k == 1 ? it.v1 : it.v2);
+                // NaN / inf positions would make the builders' binning and partition comparators undefined
+                if (!std::isfinite(v[0]) || !std::isfinite(v[1]) || !std::isfinite(v[2]))
+                    return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: vertex position is not finite");
                 dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
             }
             it.packed_id = (m << 24) | t;
@@ -764,7 +804,11 @@ int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t
     rp.spp_begin = spp_begin;
     rp.spp_count = spp_count;
     rp.seed32 = seed_hash_of(seed);
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct EventGuard {   // the two events are destroyed on every early return; `pending` takes them over at the end
+        hipEvent_t &a, &b;
+        ~EventGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } event_guard{e0, e1};
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
@@ -783,17 +827,27 @@ int render_impl(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t
             rc = stats ? (n16 ? launch_megakernel<true, true>(c, rp) : launch_megakernel<true, false>(c, rp))
                        : (n16 ? launch_megakernel<false, true>(c, rp) : launch_megakernel<false, false>(c, rp));
     }
-    if (rc) {
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        return rc;
-    }
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->pending.emplace_back(e0, e1);
+    e0 = e1 = nullptr;
     c->samples += (uint64_t)c->sc.width * c->sc.height * spp_count;
     c->accum_spp += spp_count;
     if (c->pending.size() > 4096) return collect_timings(c);
     return TRH_OK;
+}
+
+// releases everything a context owns (also the partly built context of a failing trh_init)
+void destroy_context(trh_context* c) {
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)collect_timings(c);
+    free_scene(c);
+    (void)hipFree(c->probe_buf);
+    (void)hipFree(c->counters);
+    (void)hipFree(c->ts.tile_counter);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
 }
 
 }  // namespace
@@ -825,13 +879,13 @@ int trh_init(int device, trh_context** ctx_out) {
     auto* c = new trh_context();
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(TRH_ERR_HIP, "hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { destroy_context(c); return fail(TRH_ERR_HIP, "hipStreamCreate failed"); }
     void* p = nullptr;
-    if (hipMalloc(&p, sizeof(DevCounters)) != hipSuccess) { delete c; return fail(TRH_ERR_HIP, "hipMalloc(counters) failed"); }
+    if (hipMalloc(&p, sizeof(DevCounters)) != hipSuccess) { destroy_context(c); return fail(TRH_ERR_HIP, "hipMalloc(counters) failed"); }
     c->counters = (DevCounters*)p;
     (void)hipMemset(p, 0, sizeof(DevCounters));
-    if (hipMalloc(&p, 256) != hipSuccess) { delete c; return fail(TRH_ERR_HIP, "hipMalloc(tile counter) failed"); }
-    c->tile_counter = (unsigned int*)p;
+    if (hipMalloc(&p, 256) != hipSuccess) { destroy_context(c); return fail(TRH_ERR_HIP, "hipMalloc(tile counter) failed"); }
+    c->ts.tile_counter = (unsigned int*)p;
     (void)hipMemset(p, 0, 256);
     if (const char* e = getenv("TRH_REFILL_THRESH")) {   // development knob
         const int v = atoi(e);
@@ -854,18 +908,24 @@ int trh_init(int device, trh_context** ctx_out) {
 
 int trh_shutdown(trh_context* c) {
     if (!c) return TRH_OK;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    (void)collect_timings(c);
-    free_scene(c);
-    (void)hipFree(c->counters);
-    (void)hipFree(c->tile_counter);
-    (void)hipStreamDestroy(c->stream);
-    delete c;
+    destroy_context(c);
     return TRH_OK;
 }
 
-int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
+}  // extern "C"
+
+namespace {
+
+// the device arrays of a linear-BVH build that no context has adopted (yet) are released on every return path
+struct DeviceBvhGuard {
+    lbvh::DeviceBvh& d;
+    ~DeviceBvhGuard() { lbvh::release(d); }
+};
+
+// trh_scene_upload proper. `shared` (may be NULL): a host-built acceleration structure of this very scene that the
+// caller built once for several devices (trh_group_scene_upload); used instead of building when the context's builder
+// is the host builder.
+int scene_upload_impl(trh_context* c, const trh_scene_desc* d, const bvh::Result* shared, bool shared_from_cache, double shared_build_ms) {
     if (!c || !d) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: NULL argument");
     if (d->width == 0 || d->height == 0) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: empty frame");
     if (d->mesh_count > 256) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 256 meshes (8-bit mesh id)");
@@ -881,8 +941,11 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
 
     // ---- build the BVH: on the host (binned SAH, default) or on the device (linear BVH)
     const auto t0 = std::chrono::steady_clock::now();
-    bvh::Result r;
+    bvh::Result local;
     lbvh::DeviceBvh dev_bvh;
+    DeviceBvhGuard dev_bvh_guard{dev_bvh};
+    float *dev_nodes = nullptr, *dev_tris = nullptr;   // record arrays of a device-side build, adopted by the context
+    uint32_t* dev_nodes16 = nullptr;
     bool built_on_device = false;
     if (c->builder == TRH_BUILDER_DEVICE_LBVH && tris.size() >= lbvh::kMinTriangles) {
         std::string why;
@@ -890,20 +953,27 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
         if (brc == 0) {
             built_on_device = true;
             // the arrays stay in HBM; the host needs the leaf order (shading records) and the scalars
+            bvh::Result& r = local;
             r.prim_index.resize(tris.size());
             HIP_TRY(hipMemcpyAsync(r.prim_index.data(), dev_bvh.prim_index, tris.size() * 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             (void)hipFree(dev_bvh.prim_index);
             dev_bvh.prim_index = nullptr;
+            // from here on the context owns the three record arrays (free_scene releases them)
             c->allocs.push_back(dev_bvh.nodes);
             c->allocs.push_back(dev_bvh.nodes16);
             c->allocs.push_back(dev_bvh.tris);
+            float* const adopted_nodes = dev_bvh.nodes;
+            uint32_t* const adopted_nodes16 = dev_bvh.nodes16;
+            float* const adopted_tris = dev_bvh.tris;
             memcpy(r.frame_center, dev_bvh.frame_center, sizeof(r.frame_center));
             r.frame_scale = dev_bvh.frame_scale;
             r.fp16_inflation = dev_bvh.fp16_inflation;
             r.max_depth = dev_bvh.max_depth;
             r.max_leaf = dev_bvh.max_leaf;
             r.sah_cost = dev_bvh.sah_cost;
+            dev_bvh.nodes = nullptr; dev_bvh.nodes16 = nullptr; dev_bvh.tris = nullptr;   // nothing left for the guard
+            dev_nodes = adopted_nodes; dev_nodes16 = adopted_nodes16; dev_tris = adopted_tris;
         } else if (brc != 2) {   // 2 = deeper than the traversal stack: the host builder bounds its depth
             return fail(TRH_ERR_HIP, why.c_str());
         } else if (getenv("TRH_VERBOSE")) {
@@ -911,7 +981,10 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
         }
     }
     bool from_cache = false;
-    if (!built_on_device) bvh::build_cached(tris, r, g_bvh_cache_dir, &from_cache);
+    const bool use_shared = !built_on_device && shared != nullptr && shared->prim_index.size() == tris.size();
+    if (!built_on_device && !use_shared) bvh::build_cached(tris, local, g_bvh_cache_dir, &from_cache);
+    if (use_shared) from_cache = shared_from_cache;
+    const bvh::Result& r = use_shared ? *shared : local;
     const auto t1 = std::chrono::steady_clock::now();
     if (r.max_depth > (uint32_t)TRH_STACK_SIZE) return fail(TRH_ERR_LIMIT, "trh_scene_upload: BVH deeper than the traversal stack");
 
@@ -951,8 +1024,8 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     };
     if (use_fp16) {
         if (built_on_device) {
-            sc.nodes16 = (const uint4*)dev_bvh.nodes16;
-            drop(dev_bvh.nodes);
+            sc.nodes16 = (const uint4*)dev_nodes16;
+            drop(dev_nodes);
         } else {
             uint32_t* dq = nullptr;
             if ((rc = dev_alloc_copy(c, r.nodes16.data(), r.nodes16.size(), &dq))) return rc;
@@ -963,8 +1036,8 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
         sc.frame_inv_lim = r.frame_scale < 1.f ? 3.0e38f * r.frame_scale : 3.402823466e+38f;
     } else {
         if (built_on_device) {
-            sc.nodes = (const float4*)dev_bvh.nodes;
-            drop(dev_bvh.nodes16);
+            sc.nodes = (const float4*)dev_nodes;
+            drop(dev_nodes16);
         } else {
             if ((rc = dev_alloc_copy(c, r.nodes.data(), r.nodes.size(), &dp))) return rc;
             sc.nodes = (const float4*)dp;
@@ -974,7 +1047,7 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
         sc.frame_inv_lim = 3.402823466e+38f;
     }
     if (built_on_device) {
-        sc.tris = (const float4*)dev_bvh.tris;
+        sc.tris = (const float4*)dev_tris;
     } else {
         if ((rc = dev_alloc_copy(c, r.tris.data(), r.tris.size(), &dp))) return rc;
         sc.tris = (const float4*)dp;
@@ -1059,9 +1132,15 @@ int trh_scene_upload(trh_context* c, const trh_scene_desc* d) {
     c->bvh.from_cache = from_cache ? 1u : 0u;
     c->bvh.device_build_ms = built_on_device ? dev_bvh.device_ms : 0.0;
     c->bvh.sah_cost = r.sah_cost;
-    c->bvh.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    c->bvh.build_ms = use_shared ? shared_build_ms : std::chrono::duration<double, std::milli>(t1 - t0).count();
     return TRH_OK;
 }
+
+}  // namespace
+
+extern "C" {
+
+int trh_scene_upload(trh_context* c, const trh_scene_desc* d) { return scene_upload_impl(c, d, nullptr, false, 0.0); }
 
 int trh_bvh_build_host(const trh_scene_desc* d, trh_bvh_info* info_out, uint64_t* hash_out, uint64_t* violations_out) {
     if (!d || !violations_out) return fail(TRH_ERR_INVALID_ARG, "trh_bvh_build_host: NULL argument");
@@ -1218,12 +1297,7 @@ int trh_bind_accum_buffer(trh_context* c, void* dptr, size_t nbytes) {
 int trh_resolve(trh_context* c, float* rgba_host, uint64_t* samples_out) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_resolve: ctx is NULL");
     if (!c->has_scene) return fail(TRH_ERR_STATE, "trh_resolve: no scene");
-    HIP_TRY(hipSetDevice(c->device));
-    const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
-    hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, c->resolved, n);
-    HIP_TRY(hipGetLastError());
-    if (rgba_host) HIP_TRY(hipMemcpyAsync(rgba_host, c->resolved, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = trh_internal::resolve_from(c, c->accum, rgba_host)) return rc;
     if (samples_out) *samples_out = c->accum_spp;
     return TRH_OK;
 }
@@ -1231,14 +1305,7 @@ int trh_resolve(trh_context* c, float* rgba_host, uint64_t* samples_out) {
 int trh_present_bgra8(trh_context* c, int tonemap, float exposure, uint32_t* bgra_host) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_present_bgra8: ctx is NULL");
     if (!c->has_scene) return fail(TRH_ERR_STATE, "trh_present_bgra8: no scene");
-    if (tonemap < TRH_TONEMAP_NONE || tonemap > TRH_TONEMAP_ACES) return fail(TRH_ERR_INVALID_ARG, "trh_present_bgra8: unknown tonemap");
-    HIP_TRY(hipSetDevice(c->device));
-    const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
-    hipLaunchKernelGGL(k_present, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, c->bitmap, c->sc.width, c->sc.height, tonemap, exposure);
-    HIP_TRY(hipGetLastError());
-    if (bgra_host) HIP_TRY(hipMemcpyAsync(bgra_host, c->bitmap, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return TRH_OK;
+    return trh_internal::present_from(c, c->accum, tonemap, exposure, bgra_host);
 }
 
 int trh_primary_hits(trh_context* c, uint32_t* ids_host, float* t_host, float* uv_host) {
@@ -1246,18 +1313,16 @@ int trh_primary_hits(trh_context* c, uint32_t* ids_host, float* t_host, float* u
     if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_primary_hits: scene and camera must be uploaded first");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
-    void *d_ids = nullptr, *d_t = nullptr, *d_uv = nullptr;
-    HIP_TRY(hipMalloc(&d_ids, (size_t)n * 4));
-    HIP_TRY(hipMalloc(&d_t, (size_t)n * 4));
-    HIP_TRY(hipMalloc(&d_uv, (size_t)n * 8));
-    hipLaunchKernelGGL(c->sc.nodes16 ? k_primary_hits<true> : k_primary_hits<false>, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, (uint32_t*)d_ids, (float*)d_t, (float2*)d_uv);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(ids_host, d_ids, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && t_host) e = hipMemcpyAsync(t_host, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && uv_host) e = hipMemcpyAsync(uv_host, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_ids); (void)hipFree(d_t); (void)hipFree(d_uv);
-    if (e != hipSuccess) return fail(TRH_ERR_HIP, std::string("trh_primary_hits: ") + hipGetErrorString(e));
+    if (int prc = ensure_probe_buffer(c, (size_t)n * 16)) return prc;   // ids | t | uv, freed with the context
+    uint32_t* d_ids = (uint32_t*)c->probe_buf;
+    float* d_t = (float*)c->probe_buf + n;
+    float2* d_uv = (float2*)((float*)c->probe_buf + 2 * (size_t)n);
+    hipLaunchKernelGGL(c->sc.nodes16 ? k_primary_hits<true> : k_primary_hits<false>, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, d_ids, d_t, d_uv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ids_host, d_ids, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (t_host) HIP_TRY(hipMemcpyAsync(t_host, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (uv_host) HIP_TRY(hipMemcpyAsync(uv_host, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return TRH_OK;
 }
 
@@ -1266,14 +1331,12 @@ int trh_sample_radiance(trh_context* c, uint32_t sample_index, uint64_t seed, fl
     if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_sample_radiance: scene and camera must be uploaded first");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
-    void* d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_out, (size_t)n * sizeof(float4)));
-    hipLaunchKernelGGL(c->sc.nodes16 ? k_sample_radiance<true> : k_sample_radiance<false>, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, sample_index, seed_hash_of(seed), (float4*)d_out);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(rgba_host, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_out);
-    if (e != hipSuccess) return fail(TRH_ERR_HIP, std::string("trh_sample_radiance: ") + hipGetErrorString(e));
+    if (int prc = ensure_probe_buffer(c, (size_t)n * sizeof(float4))) return prc;   // freed with the context
+    float4* d_out = (float4*)c->probe_buf;
+    hipLaunchKernelGGL(c->sc.nodes16 ? k_sample_radiance<true> : k_sample_radiance<false>, dim3((n + TRH_BLOCK - 1) / TRH_BLOCK), dim3(TRH_BLOCK), 0, c->stream, c->sc, sample_index, seed_hash_of(seed), d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgba_host, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return TRH_OK;
 }
 
@@ -1323,3 +1386,53 @@ int trh_get_bvh_info(trh_context* c, trh_bvh_info* out) {
 }
 
 }  // extern "C"
+
+// ---- internal interface of the multi-device group (ctx_internal.h, tracy_group.hip)
+namespace trh_internal {
+
+int fail(int code, const std::string& msg) { return ::fail(code, msg); }
+int device_of(const trh_context* c) { return c->device; }
+hipStream_t stream_of(const trh_context* c) { return c->stream; }
+int builder_of(const trh_context* c) { return c->builder; }
+float* accum_of(const trh_context* c, size_t* float_count) {
+    if (float_count) *float_count = (size_t)c->sc.width * c->sc.height * 4;
+    return (float*)c->accum;
+}
+
+int build_host_shared(const trh_scene_desc* d, bvh::Result& out, bool& from_cache, double& build_ms) {
+    if (!d) return fail(TRH_ERR_INVALID_ARG, "trh_group_scene_upload: NULL argument");
+    std::vector<bvh::InputTriangle> tris;
+    bool any_normal_map = false;
+    if (int frc = flatten_triangles(d, tris, any_normal_map)) return frc;
+    const auto t0 = std::chrono::steady_clock::now();
+    bvh::build_cached(tris, out, g_bvh_cache_dir, &from_cache);
+    build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return TRH_OK;
+}
+
+int scene_upload_shared(trh_context* c, const trh_scene_desc* d, const bvh::Result* shared, bool from_cache, double build_ms) {
+    return scene_upload_impl(c, d, shared, from_cache, build_ms);
+}
+
+int resolve_from(trh_context* c, const void* sums, float* rgba_host) {
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
+    hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4*)sums, c->resolved, n);
+    HIP_TRY(hipGetLastError());
+    if (rgba_host) HIP_TRY(hipMemcpyAsync(rgba_host, c->resolved, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TRH_OK;
+}
+
+int present_from(trh_context* c, const void* sums, int tonemap, float exposure, uint32_t* bgra_host) {
+    if (tonemap < TRH_TONEMAP_NONE || tonemap > TRH_TONEMAP_ACES) return fail(TRH_ERR_INVALID_ARG, "trh_present_bgra8: unknown tonemap");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)(c->sc.width * c->sc.height);
+    hipLaunchKernelGGL(k_present, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4*)sums, c->bitmap, c->sc.width, c->sc.height, tonemap, exposure);
+    HIP_TRY(hipGetLastError());
+    if (bgra_host) HIP_TRY(hipMemcpyAsync(bgra_host, c->bitmap, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TRH_OK;
+}
+
+}  // namespace trh_internal

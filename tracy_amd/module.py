@@ -178,3 +178,110 @@ class HipTrace:
             self.Shutdown()
         except Exception:
             pass
+
+
+def split_samples(spp_begin, spp_count, ngpus, g):
+    """trh_split_samples: the sample range device g of ngpus renders of a call of spp_count samples (host arithmetic)."""
+    b, n = C.c_uint32(), C.c_uint32()
+    capi.hip_lib().trh_split_samples(spp_begin, spp_count, ngpus, g, C.byref(b), C.byref(n))
+    return b.value, n.value
+
+
+class HipTraceGroup:
+    """The module over the N GPUs of a node, driven by one host thread (trh_group_*, include/tracy_hip.h): the sample
+    indices of every render call are split across the devices, OnRender / resolve run the one RCCL reduce to device 0.
+    Same life cycle as HipTrace / TracyModule."""
+    eCreate, eResize, eCameraCut, eDestroy = range(4)
+
+    def __init__(self, ngpus=0, spp_per_update=None, seed=DEFAULT_SEED, builder=None):
+        self.ngpus_requested = ngpus
+        self.builder = builder
+        self.seed = seed
+        self.spp_per_update = spp_per_update
+        self._lib = None
+        self._grp = C.c_void_p()
+        self.ngpus = 0
+        self._next_sample = 0
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc:
+            raise HipError(f"trh error {rc}: {self._lib.trh_last_error().decode()}")
+
+    def GetModuleName(self):
+        return f"HIP Raytracing [{self.ngpus} x MI355X gfx950]"
+
+    def Startup(self, scene, window=None):
+        self._lib = capi.hip_lib()
+        n = C.c_int(0)
+        self._check(self._lib.trh_group_init(self.ngpus_requested, C.byref(n), C.byref(self._grp)))
+        self.ngpus = n.value
+        if self.spp_per_update is None:
+            self.spp_per_update = self.ngpus   # one sample per device and update
+        if self.builder is not None:
+            self._check(self._lib.trh_group_set_builder(self._grp, int(self.builder)))
+        self._check(self._lib.trh_group_scene_upload(self._grp, C.byref(scene.desc)))
+        self.width, self.height = scene.width, scene.height
+        self._upload_camera(scene)
+        self._next_sample = 0
+        return True
+
+    def Shutdown(self):
+        if self._lib is not None and self._grp:
+            self._lib.trh_group_shutdown(self._grp)
+            self._grp = C.c_void_p()
+
+    def _upload_camera(self, scene):
+        eye, ivp = scene.eye_ivp()
+        eye = np.ascontiguousarray(eye, dtype=np.float32)
+        ivp = np.ascontiguousarray(ivp, dtype=np.float32)
+        self._check(self._lib.trh_group_set_camera(self._grp, eye.ctypes.data_as(C.POINTER(C.c_float)), ivp.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def OnUpdate(self, scene=None, dt=0.0):
+        self.render(self._next_sample, self.spp_per_update)
+        self._next_sample += self.spp_per_update
+
+    def OnEvent(self, event, scene=None, window=None):
+        if event == self.eCameraCut:
+            if scene is not None:
+                self._upload_camera(scene)
+            self._check(self._lib.trh_group_reset_accumulation(self._grp))
+            self._next_sample = 0
+
+    def OnRender(self, window=None):
+        return self.resolve()[0]
+
+    def GetRayCount(self, reset=False):
+        return self.stats(reset)["rays"]
+
+    def render(self, spp_begin, spp_count, seed=None):
+        self._check(self._lib.trh_group_render(self._grp, spp_begin, spp_count, self.seed if seed is None else seed))
+
+    def synchronize(self):
+        self._check(self._lib.trh_group_synchronize(self._grp))
+
+    def reset(self):
+        self._check(self._lib.trh_group_reset_accumulation(self._grp))
+        self._next_sample = 0
+
+    def resolve(self, to_host=True):
+        n = C.c_uint64()
+        img = np.empty((self.height, self.width, 4), dtype=np.float32) if to_host else None
+        self._check(self._lib.trh_group_resolve(self._grp, img.ctypes.data_as(C.c_void_p) if to_host else None, C.byref(n)))
+        return img, n.value
+
+    def present(self, tonemap=capi.TRH_TONEMAP_SRGB, exposure=1.0):
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        self._check(self._lib.trh_group_present_bgra8(self._grp, tonemap, exposure, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def stats(self, reset=False):
+        s = capi.trh_stats()
+        self._check(self._lib.trh_group_get_stats(self._grp, C.byref(s), int(reset)))
+        return {k: getattr(s, k) for k, _ in capi.trh_stats._fields_}
+
+    def __del__(self):
+        try:
+            self.Shutdown()
+        except Exception:
+            pass
