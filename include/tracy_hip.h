@@ -189,6 +189,20 @@ int trh_render(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, uint64_
  * triangle tests, hits and texture fetches (the roofline numerator). Slower. */
 int trh_render_stats(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, uint64_t seed);
 
+/* trh_render for callers that cannot allocate. NO COUNTERPART IN THE REFERENCE: it exists for hosts that
+ * run under HIP graph capture, in tight serving loops or in harnesses that forbid hipMalloc. Same samples, same
+ * kernels and the same launch sequence as trh_render on a context that has no tile order yet (every call of
+ * >= 16 spp traces its first sample as a launch of its own), but the launch scratch -- the tile counter the
+ * persistent waves pull from, and the cost / order / key arrays and the sort's temporary storage of the
+ * cost-ordered tile hand-out -- lives in a file-scope __device__ array of 6.25 MiB that every GPU the library
+ * runs on holds until the process ends, instead of in hipMalloc'ed memory. The call performs no hipMalloc,
+ * hipFree, event creation or other allocating routine and records no launch timing (trh_stats.kernel_ms /
+ * launches do not count it; rays and samples do). Limits: megakernel pipeline only (TRH_ERR_STATE otherwise),
+ * <= 65536 spp per call, and at most 262144 tiles (1080p and 4K frames at >= 8 spp per call fit; TRH_ERR_LIMIT
+ * names the tile count otherwise). All contexts on one GPU share that GPU's array: calls that overlap on one
+ * GPU (two contexts, two threads) race; calls on different GPUs do not. */
+int trh_render_noalloc(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, uint64_t seed);
+
 int trh_synchronize(trh_context* ctx);
 
 /* Device pointer of the accumulation buffer (width*height float4, rgb sums + count) so

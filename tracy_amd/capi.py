@@ -115,6 +115,7 @@ HIP_SYMBOLS = {
     "trh_set_builder": (C.c_int, [C.c_void_p, C.c_int]),
     "trh_set_bvh_cache_dir": (C.c_int, [C.c_char_p]),
     "trh_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(trh_bvh_info)]),
+    "trh_render_noalloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "trh_group_init": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "trh_group_shutdown": (C.c_int, [C.c_void_p]),
     "trh_group_size": (C.c_int, [C.c_void_p]),

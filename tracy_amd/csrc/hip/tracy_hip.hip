@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -398,7 +399,21 @@ __global__ void k_present(const float4* __restrict__ accum, uint32_t* __restrict
 // host side of the C ABI
 // =====================================================================================
 
+// ---- scratch of trh_render_noalloc (include/tracy_hip.h): the tile counter and the tile-order arrays of ONE launch
+// sequence, in a file-scope device array instead of hipMalloc'ed memory. Every GPU the library runs on holds its own
+// copy (6.25 MiB) at its own address until the process ends; host code never uses the array's name as an address but
+// the per-device pointer trh_init obtains with hipGetSymbolAddress (g_scratch_ptr).
+constexpr uint32_t kNoAllocMaxTiles = 1u << 18;                  // 262 144 tiles: 1080p and 4K at >= 8 spp per launch fit
+constexpr size_t kNoAllocSortTempBytes = 1u << 20;               // hipcub radix-sort temporary storage for that many keys
+constexpr size_t kNoAllocArrayBytes = (size_t)kNoAllocMaxTiles * sizeof(uint32_t);
+constexpr size_t kNoAllocScratchBytes = 256 + 5 * kNoAllocArrayBytes + kNoAllocSortTempBytes;
+static __device__ __align__(256) unsigned char g_scratch[kNoAllocScratchBytes];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};   // per device: the address of that GPU's copy of g_scratch
+std::mutex g_scratch_mutex;
 
 thread_local std::string g_err;
 std::string g_bvh_cache_dir = [] { const char* e = getenv("TRH_BVH_CACHE"); return std::string(e ? e : ""); }();   // trh_set_bvh_cache_dir
@@ -428,7 +443,7 @@ uint32_t seed_hash_of(uint64_t seed) {
 
 // Scratch of one megakernel launch sequence: the tile counter the persistent waves pull from and the arrays of the
 // cost-ordered tile hand-out (tile_order.h). trh_render keeps one per context in hipMalloc'ed memory (the order is
-// reused by the next launch of the same tiling).
+// reused by the next launch of the same tiling); trh_render_noalloc lays one out in the file-scope g_scratch array.
 struct TileState {
     unsigned int* tile_counter = nullptr;
     uint32_t *cost = nullptr, *order = nullptr, *keys = nullptr, *keys_sorted = nullptr, *iota = nullptr;
@@ -887,6 +902,17 @@ int trh_init(int device, trh_context** ctx_out) {
     if (hipMalloc(&p, 256) != hipSuccess) { destroy_context(c); return fail(TRH_ERR_HIP, "hipMalloc(tile counter) failed"); }
     c->ts.tile_counter = (unsigned int*)p;
     (void)hipMemset(p, 0, 256);
+    // trh_render_noalloc: the address of THIS device's copy of the file-scope scratch array, looked up once per device
+    // with the device current (every GPU holds its own copy at its own address)
+    if (device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            void* sp = nullptr;
+            const hipError_t se = hipGetSymbolAddress(&sp, HIP_SYMBOL(g_scratch));
+            if (se != hipSuccess || !sp) { destroy_context(c); return fail(TRH_ERR_HIP, std::string("hipGetSymbolAddress(g_scratch): ") + hipGetErrorString(se)); }
+            g_scratch_ptr[device] = (unsigned char*)sp;
+        }
+    }
     if (const char* e = getenv("TRH_REFILL_THRESH")) {   // development knob
         const int v = atoi(e);
         if (v >= 1 && v <= 64) c->refill_thresh = (uint32_t)v;
@@ -1260,6 +1286,57 @@ int trh_set_pipeline(trh_context* c, int pipeline) {
 
 int trh_render(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed) { return render_impl(c, spp_begin, spp_count, seed, false); }
 int trh_render_stats(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed) { return render_impl(c, spp_begin, spp_count, seed, true); }
+
+// trh_render for callers that must not allocate (HIP graph capture, tight serving loops): the same megakernel launch
+// sequence, with the tile counter and the tile-order arrays laid out in this device's copy of g_scratch instead of
+// hipMalloc'ed memory. Calls no hipMalloc / hipFree / hipEventCreate and keeps no state between calls: the tile order of
+// the previous call is never trusted (another context on this GPU may have used the array since), so every call of
+// >= 16 spp starts with the one-sample probe launch, exactly like trh_render on a context that has no order yet.
+int trh_render_noalloc(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed) {
+    if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_render_noalloc: ctx is NULL");
+    if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_render_noalloc: scene and camera must be uploaded first");
+    if (c->pipeline != TRH_PIPELINE_MEGAKERNEL) return fail(TRH_ERR_STATE, "trh_render_noalloc: only the megakernel pipeline runs without allocations");
+    if (spp_count == 0) return TRH_OK;
+    if (spp_count > (1u << 16)) return fail(TRH_ERR_LIMIT, "trh_render_noalloc: more than 65536 samples per pixel in one call");
+    if ((uint64_t)spp_begin + spp_count > 0xffffffffull) return fail(TRH_ERR_LIMIT, "trh_render_noalloc: sample index exceeds 32 bits");
+    if (c->device >= kMaxDevices || !g_scratch_ptr[c->device]) return fail(TRH_ERR_STATE, "trh_render_noalloc: no scratch address for this device");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t wl, hl, ntiles;
+    choose_tiling(c, spp_count, wl, hl, ntiles);
+    const bool ordered = c->tile_feedback && spp_count >= 8;
+    unsigned char* const base = g_scratch_ptr[c->device];   // the device address, never the array's name
+    TileState ts;
+    ts.tile_counter = (unsigned int*)base;
+    if (ordered) {
+        if (ntiles > kNoAllocMaxTiles)
+            return fail(TRH_ERR_LIMIT, "trh_render_noalloc: this frame size and sample count need " + std::to_string(ntiles) +
+                                           " tiles, the static scratch holds " + std::to_string(kNoAllocMaxTiles) + " (use trh_render, or more samples per call)");
+        const size_t temp = tile_order::scratch_bytes(ntiles);   // a size query: allocates nothing
+        if (temp > kNoAllocSortTempBytes) return fail(TRH_ERR_LIMIT, "trh_render_noalloc: the tile sort needs more temporary storage than the static scratch reserves");
+        uint32_t* arrays = (uint32_t*)(base + 256);
+        ts.cost = arrays;
+        ts.order = arrays + (size_t)kNoAllocMaxTiles;
+        ts.keys = arrays + 2 * (size_t)kNoAllocMaxTiles;
+        ts.keys_sorted = arrays + 3 * (size_t)kNoAllocMaxTiles;
+        ts.iota = arrays + 4 * (size_t)kNoAllocMaxTiles;
+        ts.sort_temp = base + 256 + 5 * kNoAllocArrayBytes;
+        ts.sort_temp_bytes = kNoAllocSortTempBytes;
+        ts.count = ntiles;
+        ts.shape = (wl << 8) | hl;
+        ts.order_valid = false;
+        // the array keeps the last call's contents: the costs start at zero as in a fresh hipMalloc'ed + cleared array
+        HIP_TRY(hipMemsetAsync(ts.cost, 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
+    }
+    RenderParams rp{};
+    rp.spp_begin = spp_begin;
+    rp.spp_count = spp_count;
+    rp.seed32 = seed_hash_of(seed);
+    const int rc = c->sc.nodes16 ? launch_megakernel_on<false, true>(c, ts, rp, wl, hl, ordered) : launch_megakernel_on<false, false>(c, ts, rp, wl, hl, ordered);
+    if (rc) return rc;
+    c->samples += (uint64_t)c->sc.width * c->sc.height * spp_count;
+    c->accum_spp += spp_count;
+    return TRH_OK;
+}
 
 int trh_synchronize(trh_context* c) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_synchronize: ctx is NULL");

@@ -108,6 +108,10 @@ class HipTrace:
         fn = self._lib.trh_render_stats if stats else self._lib.trh_render
         self._check(fn(self._ctx, spp_begin, spp_count, self.seed if seed is None else seed))
 
+    def render_noalloc(self, spp_begin, spp_count, seed=None):
+        """trh_render_noalloc: the same launches with the launch scratch in the library's static device array."""
+        self._check(self._lib.trh_render_noalloc(self._ctx, spp_begin, spp_count, self.seed if seed is None else seed))
+
     def synchronize(self):
         self._check(self._lib.trh_synchronize(self._ctx))
 
