@@ -112,3 +112,34 @@ def test_cli_renders_the_textured_helmet_with_the_builtin_decoders(tmp_path):
     ref, _ = mod.resolve()
     mod.Shutdown()
     assert np.array_equal(img, ref[..., :3])
+
+
+@pytest.mark.gpu
+def test_cli_adaptive_updates_trace_the_same_samples(tmp_path):
+    """-spu auto (the module default): one sample for the first update, then doubling towards ~12 ms per update;
+    -async: OnUpdate only enqueues, OnRender waits; -gpus 0: every GPU of the node through trh_group_*. Whatever
+    the split into updates and devices, the sample set is the same: the image equals one trh_render of the same
+    samples up to the rounding of the per-pixel float sums."""
+    import re
+    out = str(tmp_path / "dragon.pfm")
+    r = subprocess.run([CLI, "-scene", os.path.join(ROOT, "assets/data/scenes/dragon.scn"), "-assets", os.path.join(ROOT, "assets"),
+                        "-kernel", "hip", "-width", "320", "-height", "180", "-spp", "300", "-spu", "auto", "-async", "-gpus", "0", "-out", out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"Msamples/s over (\d+) updates \((\d+) spp, last update (\d+) spp\)", r.stderr)
+    assert m, r.stderr
+    updates, spp, last = map(int, m.groups())
+    assert spp >= 300 and last > 1 and updates < spp, "the samples per update never grew"
+    with open(out, "rb") as f:
+        assert f.readline() == b"PF\n"
+        w, h = map(int, f.readline().split())
+        f.readline()
+        img = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+    from tracy_amd import Scene, HipTrace
+    sc = Scene("data/scenes/dragon.scn", 320, 180)
+    mod = HipTrace()
+    mod.Startup(sc)
+    mod.render(0, spp)
+    ref, _ = mod.resolve()
+    mod.Shutdown()
+    np.testing.assert_allclose(img, ref[..., :3], rtol=1e-5, atol=1e-6)

@@ -3,7 +3,9 @@
 // (Startup -> [OnEvent]* -> OnUpdate -> OnRender -> GetRayCount(true) -> Shutdown), same statistics
 // text ("[%.2f MRays/s @ %.2f fps]", win_raytracer.cpp:532,566). No window: the GPU box has no X
 // server. Extra flags: -width/-height (override OUT), -spp N (stop after N samples per pixel),
-// -spu K (samples per OnUpdate), -out file.pfm (linear) | file.ppm | file.png (tonemapped picture),
+// -spu K|auto (samples per OnUpdate; auto = the module's adaptive default), -gpus N (GPUs of the node to use, 0 = all: the
+// samples of every update are split across them and one RCCL reduce to GPU 0 makes the picture), -async (OnUpdate only
+// enqueues; the frame is timed as OnUpdate + OnRender), -out file.pfm (linear) | file.ppm | file.png (tonemapped picture),
 // -tonemap srgb|reinhard|aces|none and -exposure E (the reference's TRACY_TONEMAPPING / TRACY_EXPOSURE
 // build options, CMakeLists.txt:92-103), -debug basecolor|normals|metalness|roughness|emissive (the DEBUG_SHOW_*
 // build options, CMakeLists.txt:23-35), -builder sah|lbvh (host binned-SAH build, or the device-side linear BVH), -device D.
@@ -102,9 +104,9 @@ int main(int argc, char** argv) {
     uint32_t WIDTH = 640, HEIGHT = 480;   // win_raytracer.cpp:439-440
     std::string scene_path = "data/default.scn", kernelname = "hip", out_path, asset_root = ".";
     uint32_t spp = 64, spu = 1;
-    int device = 0, tonemap = TRH_TONEMAP_SRGB, debug_view = TRH_VIEW_NONE, builder = TRH_BUILDER_HOST_SAH;
+    int device = -1, gpus = 1, tonemap = TRH_TONEMAP_SRGB, debug_view = TRH_VIEW_NONE, builder = TRH_BUILDER_HOST_SAH;
     float exposure = 1.f;
-    bool override_size = false;
+    bool override_size = false, async_update = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a(argv[i]);
         auto next = [&](const char* def) { return (i + 1 < argc) ? argv[++i] : def; };
@@ -113,7 +115,9 @@ int main(int argc, char** argv) {
         else if (a == "-width") { WIDTH = (uint32_t)atoi(next("0")); override_size = true; }
         else if (a == "-height") { HEIGHT = (uint32_t)atoi(next("0")); override_size = true; }
         else if (a == "-spp") spp = (uint32_t)atoi(next("64"));
-        else if (a == "-spu") spu = (uint32_t)atoi(next("1"));
+        else if (a == "-spu") { const std::string t = next("1"); spu = t == "auto" ? 0u : std::max(1u, (uint32_t)atoi(t.c_str())); }
+        else if (a == "-gpus") gpus = atoi(next("1"));
+        else if (a == "-async") async_update = true;
         else if (a == "-out") out_path = next("");
         else if (a == "-assets") asset_root = next(".");
         else if (a == "-device") device = atoi(next("0"));
@@ -133,7 +137,8 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Invalid kernel choice: should be one in [hip]\n");
         return EXIT_FAILURE;
     }
-    if (spu == 0) spu = 1;
+    // a group uses devices 0..N-1; one particular GPU is chosen by making it the only visible one (before the first HIP call)
+    if (device >= 0) setenv("HIP_VISIBLE_DEVICES", std::to_string(device).c_str(), 1);
 
     HostScene world;
     if (!world.Init(scene_path.c_str(), asset_root.c_str(), WIDTH, HEIGHT, override_size)) {
@@ -141,7 +146,8 @@ int main(int argc, char** argv) {
         return EXIT_FAILURE;
     }
     handle_t win{WIDTH, HEIGHT};
-    HipTrace kernel(device, spu);
+    HipTrace kernel(gpus, spu);
+    kernel.SetSynchronousUpdate(!async_update);
     kernel.SetTonemap(tonemap, exposure);
     kernel.SetDebugView(debug_view);
     kernel.SetBuilder(builder);
@@ -149,8 +155,8 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Kernel failed to initialize\n");   // win_raytracer.cpp:572-575
         return EXIT_FAILURE;
     }
-    fprintf(stderr, "%s: '%s' %ux%u, %u objects, %u triangles, kernel '%s'\n", argv[0], world.GetName().c_str(), WIDTH, HEIGHT,
-            world.GetObjectCount(), world.GetTriCount(), kernel.GetModuleName());
+    fprintf(stderr, "%s: '%s' %ux%u, %u objects, %u triangles, kernel '%s' on %d GPU(s)\n", argv[0], world.GetName().c_str(), WIDTH, HEIGHT,
+            world.GetObjectCount(), world.GetTriCount(), kernel.GetModuleName(), kernel.GetGpuCount());
 
     using clock = std::chrono::steady_clock;
     double trace_s = 0.0, stat_s = 0.0;
@@ -159,12 +165,13 @@ int main(int argc, char** argv) {
     while (kernel.GetSampleCount() < spp) {
         const auto t0 = clock::now();
         kernel.OnUpdate(world, 0.f);
+        if (async_update) kernel.OnRender(&win);   // the update is still in flight: the frame ends when its picture is there
         const double dt = std::chrono::duration<double>(clock::now() - t0).count();
         trace_s += dt;
         stat_s += dt;
         ++frames;
         ++stat_frames;
-        kernel.OnRender(&win);
+        if (!async_update) kernel.OnRender(&win);
         if (stat_s > 1.0 || stat_frames > 100) {   // win_raytracer.cpp:521-553
             const uint64_t rays = kernel.GetRayCount64(true);
             rays_total += rays;
@@ -176,6 +183,8 @@ int main(int argc, char** argv) {
     rays_total += kernel.GetRayCount64(true);
     kernel.OnRender(&win);
     fprintf(stderr, "*** Performance: %.2f MRays/s and %.2f fps on average\n", rays_total * 1e-6 / trace_s, frames / trace_s);
+    fprintf(stderr, "*** %.2f Msamples/s over %u updates (%u spp, last update %u spp)\n", (double)WIDTH * HEIGHT * kernel.GetSampleCount() * 1e-6 / trace_s,
+            frames, kernel.GetSampleCount(), kernel.GetSamplesPerUpdate());
     bool ok = true;
     if (!out_path.empty()) {
         const std::string ext = out_path.size() > 4 ? out_path.substr(out_path.size() - 4) : std::string();

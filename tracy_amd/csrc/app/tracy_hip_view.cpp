@@ -25,8 +25,8 @@ using namespace tracy_hip;
 int main(int argc, char** argv) {
     uint32_t WIDTH = 640, HEIGHT = 480;   // win_raytracer.cpp:439-440
     std::string scene_path = "data/default.scn", kernelname = "hip", asset_root = ".";
-    uint32_t spu = 1;
-    int device = 0;
+    uint32_t spu = 0;   // 0 = adaptive (the module default)
+    int device = -1, gpus = 1;
     bool override_size = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a(argv[i]);
@@ -35,7 +35,8 @@ int main(int argc, char** argv) {
         else if (a == "-kernel") kernelname = next("");
         else if (a == "-width") { WIDTH = (uint32_t)atoi(next("0")); override_size = true; }
         else if (a == "-height") { HEIGHT = (uint32_t)atoi(next("0")); override_size = true; }
-        else if (a == "-spu") spu = (uint32_t)atoi(next("1"));
+        else if (a == "-spu") { const std::string t = next("auto"); spu = t == "auto" ? 0u : (uint32_t)atoi(t.c_str()); }
+        else if (a == "-gpus") gpus = atoi(next("1"));
         else if (a == "-assets") asset_root = next(".");
         else if (a == "-device") device = atoi(next("0"));
     }
@@ -43,7 +44,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Invalid kernel choice: should be one in [hip]\n");
         return EXIT_FAILURE;
     }
-    if (spu == 0) spu = 1;
+    if (device >= 0) setenv("HIP_VISIBLE_DEVICES", std::to_string(device).c_str(), 1);   // before the first HIP call
 
     Display* dpy = XOpenDisplay(nullptr);
     if (!dpy) {
@@ -73,7 +74,7 @@ int main(int argc, char** argv) {
     GC gc = DefaultGC(dpy, screen);
 
     handle_t handle{WIDTH, HEIGHT};
-    HipTrace kernel(device, spu);
+    HipTrace kernel(gpus, spu);
     if (!kernel.Startup(&handle, world)) {
         fprintf(stderr, "Kernel failed to initialize\n");
         XDestroyWindow(dpy, win);

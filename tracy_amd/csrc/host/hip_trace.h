@@ -12,6 +12,7 @@
 // initialize", win_raytracer.cpp:572-575); run-time device errors are logged and abort, like
 // CUDAAssert (cuda_log.h:19-32). There is no CPU fallback.
 #pragma once
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -146,29 +147,35 @@ bool FlattenCamera(const SceneT& scene, FlatScene& out) {
 template <class SceneT, class Base = TracyModuleT<SceneT>, class WindowT = WindowHandle, class EventT = TracyEvent>
 class HipTraceT final : public Base {
 public:
-    // samples traced per OnUpdate; the reference traces 1 (cpu_trace.cpp:55-65)
-    explicit HipTraceT(int device = 0, uint32_t spp_per_update = 1) : device_(device), spp_per_update_(spp_per_update) {}
+    // ngpus: GPUs of the node to use (devices 0..ngpus-1, <= 0 = all of them); one host thread drives them through
+    // trh_group_* (one GPU: the group is the plain single-device context).
+    // spp_per_update: samples traced per OnUpdate over all GPUs. The reference traces 1 (cpu_trace.cpp:55-65); at GPU
+    // rates a 1-spp update is dominated by the launch's fixed cost (dragon 1080p: 0.77 ms at 1 spp = 2.7 Gsamples/s
+    // against 11.5 Gsamples/s at 64 spp), so the default 0 means ADAPTIVE: one sample per GPU for the first update after
+    // Startup / eCameraCut (the picture reacts at once), then doubling while an update stays under kTargetUpdateMs.
+    explicit HipTraceT(int ngpus = 1, uint32_t spp_per_update = 0) : ngpus_requested_(ngpus), spp_per_update_(spp_per_update) {}
 
     bool Startup(const WindowT in_Window, const SceneT& in_Scene) override {
         (void)in_Window;
-        if (trh_init(device_, &ctx_) != TRH_OK) return Fail("trh_init");
-        if (trh_set_builder(ctx_, builder_) != TRH_OK) return Fail("trh_set_builder");
+        if (trh_group_init(ngpus_requested_, &ngpus_, &group_) != TRH_OK) return Fail("trh_group_init");
+        if (trh_group_set_builder(group_, builder_) != TRH_OK) return Fail("trh_group_set_builder");
         FlatScene flat;
         if (!FlattenScene(in_Scene, flat)) return Fail("FlattenScene");
-        if (trh_scene_upload(ctx_, &flat.desc) != TRH_OK) return Fail("trh_scene_upload");
-        if (trh_set_camera(ctx_, flat.eye, flat.inv_view_proj) != TRH_OK) return Fail("trh_set_camera");
-        if (trh_set_debug_view(ctx_, debug_view_, flat.view3) != TRH_OK) return Fail("trh_set_debug_view");
+        if (trh_group_scene_upload(group_, &flat.desc) != TRH_OK) return Fail("trh_group_scene_upload");
+        if (trh_group_set_camera(group_, flat.eye, flat.inv_view_proj) != TRH_OK) return Fail("trh_group_set_camera");
+        if (trh_group_set_debug_view(group_, debug_view_, flat.view3) != TRH_OK) return Fail("trh_group_set_debug_view");
         width_ = flat.desc.width;
         height_ = flat.desc.height;
         image_.assign(static_cast<size_t>(width_) * height_ * 4, 0.f);
         bitmap_.assign(static_cast<size_t>(width_) * height_, 0u);
         next_sample_ = 0;
+        auto_spp_ = static_cast<uint32_t>(ngpus_);
         return true;
     }
 
     void Shutdown() override {
-        if (ctx_) trh_shutdown(ctx_);
-        ctx_ = nullptr;
+        if (group_) trh_group_shutdown(group_);
+        group_ = nullptr;
     }
 
     void OnUpdate(const SceneT& in_Scene, float in_DeltaTime) override {
@@ -176,25 +183,42 @@ public:
         if (camera_dirty_) {   // pattern of CUDADetails::Update (cuda_details.cpp:206-215)
             FlatScene cam;
             if (FlattenCamera(in_Scene, cam)) {
-                Check(trh_set_camera(ctx_, cam.eye, cam.inv_view_proj), "trh_set_camera");
-                Check(trh_set_debug_view(ctx_, debug_view_, cam.view3), "trh_set_debug_view");
+                Check(trh_group_set_camera(group_, cam.eye, cam.inv_view_proj), "trh_group_set_camera");
+                Check(trh_group_set_debug_view(group_, debug_view_, cam.view3), "trh_group_set_debug_view");
             }
-            Check(trh_reset_accumulation(ctx_), "trh_reset_accumulation");
+            Check(trh_group_reset_accumulation(group_), "trh_group_reset_accumulation");
             next_sample_ = 0;
+            auto_spp_ = static_cast<uint32_t>(ngpus_);   // react at once, then ramp up again
             camera_dirty_ = false;
         }
-        Check(trh_render(ctx_, next_sample_, spp_per_update_, kSeed), "trh_render");
-        Check(trh_synchronize(ctx_), "trh_synchronize");   // OnUpdate is synchronous: main() times it (win_raytracer.cpp:511-515)
-        next_sample_ += spp_per_update_;
+        const uint32_t spp = spp_per_update_ ? spp_per_update_ : auto_spp_;
+        const auto t0 = std::chrono::steady_clock::now();
+        Check(trh_group_render(group_, next_sample_, spp, kSeed), "trh_group_render");
+        next_sample_ += spp;
+        if (synchronous_update_) {
+            // main() times this call (win_raytracer.cpp:511-515) and derives MRays/s from it: return when the pass is done
+            Check(trh_group_synchronize(group_), "trh_group_synchronize");
+            Adapt(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), spp);
+        } else {
+            // the launches stay in flight; OnRender / GetRayCount wait for them. A host that uses this must time
+            // OnUpdate + OnRender together (tracy_hip_cli does).
+            if (unmeasured_spp_ == 0) unmeasured_since_ = t0;
+            unmeasured_spp_ += spp;
+        }
     }
 
     // The reference modules tonemap into their Bitmap and paint the window here
     // (cpu_details.cpp:201-248). The picture is produced on the device by trh_present_bgra8
     // (8 MB at 1080p instead of the 33 MB float image) and kept for the caller (GetBitmap); a
-    // host with a display blits it (XPutImage / StretchDIBits of bitmap.cpp:84-110).
+    // host with a display blits it (XPutImage / StretchDIBits of bitmap.cpp:84-110). With several GPUs this is
+    // where the one exchange step runs (RCCL reduce to device 0).
     void OnRender(const WindowT in_Window) override {
         (void)in_Window;
-        Check(trh_present_bgra8(ctx_, tonemap_, exposure_, bitmap_.data()), "trh_present_bgra8");
+        Check(trh_group_present_bgra8(group_, tonemap_, exposure_, bitmap_.data()), "trh_group_present_bgra8");
+        if (unmeasured_spp_) {   // asynchronous updates: the present has waited for them
+            Adapt(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - unmeasured_since_).count(), unmeasured_spp_);
+            unmeasured_spp_ = 0;
+        }
     }
 
     void OnEvent(EventT in_Event, const WindowT in_Window, const SceneT& in_Scene) override {
@@ -207,20 +231,19 @@ public:
 
     // u32 in the interface (src/module.h:53); saturates instead of wrapping
     uint32_t GetRayCount(bool in_ShouldReset = false) override {
-        trh_stats st{};
-        Check(trh_get_stats(ctx_, &st, in_ShouldReset ? 1 : 0), "trh_get_stats");
-        return st.rays > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(st.rays);
+        const uint64_t rays = GetRayCount64(in_ShouldReset);
+        return rays > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(rays);
     }
     uint64_t GetRayCount64(bool in_ShouldReset = false) {
         trh_stats st{};
-        Check(trh_get_stats(ctx_, &st, in_ShouldReset ? 1 : 0), "trh_get_stats");
+        Check(trh_group_get_stats(group_, &st, in_ShouldReset ? 1 : 0), "trh_group_get_stats");
         return st.rays;
     }
 
     // linear mean image (width*height*4 floats, row 0 = bottom row, .w = sample count), resolved on demand
     const float* GetImage() {
         uint64_t n = 0;
-        Check(trh_resolve(ctx_, image_.data(), &n), "trh_resolve");
+        Check(trh_group_resolve(group_, image_.data(), &n), "trh_group_resolve");
         return image_.data();
     }
     // picture of the last OnRender: width*height 0x00RRGGBB, row 0 = top row
@@ -228,21 +251,44 @@ public:
     // the reference fixes these at compile time (TRACY_TONEMAPPING / TRACY_EXPOSURE, CMakeLists.txt:92-103)
     void SetTonemap(int in_Tonemap, float in_Exposure) { tonemap_ = in_Tonemap; exposure_ = in_Exposure; }
     // the reference's DEBUG_SHOW_* build switches (CMakeLists.txt:23-35) at run time; call before Startup or send eCameraCut
-    void SetDebugView(int in_View) { debug_view_ = in_View; camera_dirty_ = ctx_ != nullptr; }
+    void SetDebugView(int in_View) { debug_view_ = in_View; camera_dirty_ = group_ != nullptr; }
     // acceleration-structure builder of the next Startup: TRH_BUILDER_HOST_SAH (default) or TRH_BUILDER_DEVICE_LBVH
     void SetBuilder(int in_Builder) { builder_ = in_Builder; }
+    // false: OnUpdate only enqueues (see OnUpdate); true (default): OnUpdate returns when its samples are traced
+    void SetSynchronousUpdate(bool in_Synchronous) { synchronous_update_ = in_Synchronous; }
     uint32_t GetWidth() const { return width_; }
     uint32_t GetHeight() const { return height_; }
     uint32_t GetSampleCount() const { return next_sample_; }
-    trh_context* GetContext() { return ctx_; }
+    uint32_t GetSamplesPerUpdate() const { return spp_per_update_ ? spp_per_update_ : auto_spp_; }
+    int GetGpuCount() const { return ngpus_; }
+    trh_group* GetGroup() { return group_; }
+    trh_context* GetContext() {   // the root device's context (parity probes, BVH info)
+        trh_context* c = nullptr;
+        if (group_) trh_group_context(group_, 0, &c);
+        return c;
+    }
 
 private:
     static constexpr uint64_t kSeed = 0xABCDEFull;   // initrand() (src/random.h:66-69)
+    static constexpr double kTargetUpdateMs = 12.0;  // adaptive mode: an update of about one 60-Hz frame
+    static constexpr uint32_t kMaxAutoSpp = 4096;
+
+    // adaptive samples per update: `spp` samples took `ms`; grow towards kTargetUpdateMs, at most doubling per step,
+    // in multiples of the GPU count (every device gets the same share)
+    void Adapt(double ms, uint32_t spp) {
+        if (spp_per_update_ != 0 || spp == 0 || !(ms > 0.0)) return;
+        const double want = kTargetUpdateMs * static_cast<double>(spp) / ms;
+        const uint32_t n = static_cast<uint32_t>(ngpus_);
+        uint32_t next = want >= static_cast<double>(kMaxAutoSpp) ? kMaxAutoSpp : static_cast<uint32_t>(want);
+        if (next > auto_spp_ * 2u) next = auto_spp_ * 2u;
+        next -= next % n;
+        auto_spp_ = next < n ? n : next;
+    }
 
     bool Fail(const char* what) {
         fprintf(stderr, "[HipTrace] %s failed: %s\n", what, trh_last_error());
-        if (ctx_) trh_shutdown(ctx_);
-        ctx_ = nullptr;
+        if (group_) trh_group_shutdown(group_);
+        group_ = nullptr;
         return false;
     }
     void Check(int rc, const char* what) {
@@ -252,9 +298,12 @@ private:
         }
     }
 
-    int device_ = 0;
-    uint32_t spp_per_update_ = 1;
-    trh_context* ctx_ = nullptr;
+    int ngpus_requested_ = 1, ngpus_ = 0;
+    uint32_t spp_per_update_ = 0, auto_spp_ = 1;
+    bool synchronous_update_ = true;
+    uint32_t unmeasured_spp_ = 0;
+    std::chrono::steady_clock::time_point unmeasured_since_{};
+    trh_group* group_ = nullptr;
     uint32_t width_ = 0, height_ = 0, next_sample_ = 0;
     bool camera_dirty_ = false;
     std::vector<float> image_;
