@@ -6,8 +6,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path (trh_render) over the whole frame for --spp-per-step new
-samples per pixel on every rank (weak scaling: disjoint global sample-index blocks per rank).
+Default workload = BASELINE.json configs[3] as it is written: 4096 samples per pixel in all, sample-
+partitioned over the N GPUs -- rank g owns the global sample indices [g*4096/N, (g+1)*4096/N)
+(sharding.split_total_spp) -- and every rank traces its share in K equal steps (STRONG scaling:
+the total work is fixed; 1 GPU, 20 steps: 204-205 spp per step). One step = one pass of the hot
+path (trh_render) over the whole frame. --spp-per-step S switches to the weak-scaling form
+(every rank traces S new samples per pixel per step, disjoint round-robin blocks).
 The timed region holds exactly K steps on every rank plus the path's one exchange step (sum-
 reduce of the float4 accumulation buffer to rank 0 over RCCL) and the device-side resolve;
 no PCIe transfer is inside it. Rank 0 prints ONE JSON line.
@@ -66,12 +70,33 @@ def cpu_baseline(scene_name, width, height, budget_s=12.0):
             "kind": "port", "sample": f"{scene_name} {width}x{height}, {n} spp (whole frames), reference kd-tree, OpenMP {threads} threads, {dt:.1f} s"}
 
 
+def psnr_vs_oracle(mod, scene, spp):
+    """PSNR of the module's image against the CPU oracle's at equal spp (same sample set), both sRGB-encoded and
+    clamped to [0, 1] -- the north_star's correctness figure (b), at a sample count the oracle finishes in seconds."""
+    from oracle.oracle import CpuRef
+
+    def srgb(x):
+        x = np.clip(x.astype(np.float64), 0.0, 1.0)
+        return np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1 / 2.4) - 0.055)
+
+    mod.bind_accum_buffer(None, 0)
+    mod.reset()
+    mod.render(0, spp)
+    img, _ = mod.resolve()
+    ref = CpuRef(scene)
+    ref.render(0, spp)
+    mse = float(np.mean((srgb(img[..., :3]) - srgb(ref.output())) ** 2))
+    return 200.0 if mse == 0.0 else 10.0 * np.log10(1.0 / mse)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--total-spp", type=int, default=4096, help="samples per pixel of the whole job (BASELINE.json configs[3]), split over ranks and steps")
+    ap.add_argument("--spp-per-step", type=int, default=None, help="override: weak scaling, every rank traces this many samples per step")
+    ap.add_argument("--psnr-spp", type=int, default=16, help="rank 0, N=1, outside the timed region: PSNR against the CPU oracle at this many spp (0 = skip)")
     ap.add_argument("--scene", default="dragon")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -106,7 +131,27 @@ def main():
     scene = Scene(f"data/scenes/{args.scene}.scn", args.width, args.height)
     mod = HipTrace(device=local_rank, pipeline=args.pipeline)
     mod.Startup(scene)
-    W, H, S = scene.width, scene.height, args.spp_per_step
+    W, H = scene.width, scene.height
+    weak = args.spp_per_step is not None
+    if weak:
+        S = args.spp_per_step                      # samples per launch of the instrumented / roofline pass
+
+        def step_range(k):                         # k counts warm-up and timed steps alike
+            return sharding.step_sample_range(rank, world, k, S)
+    else:
+        my_begin, my_count = sharding.split_total_spp(rank, world, args.total_spp)
+        if my_count < args.steps:
+            raise SystemExit(f"--total-spp {args.total_spp} over {world} ranks and {args.steps} steps leaves steps without samples")
+        S = -(-my_count // args.steps)             # the larger of the two step sizes (ceil)
+
+        def step_range(k):
+            # warm-up steps trace samples beyond the job's range (same launch shape); timed step j = k - warmup
+            # owns [j*my_count/K, (j+1)*my_count/K) of this rank's share
+            if k < args.warmup:
+                return args.total_spp + (k * world + rank) * S, S
+            j = k - args.warmup
+            lo, hi = (j * my_count) // args.steps, ((j + 1) * my_count) // args.steps
+            return my_begin + lo, hi - lo
 
     # accumulation buffer owned by torch so that torch.distributed (RCCL) can reduce it in place
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -119,7 +164,7 @@ def main():
 
     # ---- instrumented pass (untimed): the roofline numerator for one launch of this workload
     mod.stats(reset=True)
-    mod.render(*sharding.step_sample_range(rank, world, 0, S), stats=True)
+    mod.render(step_range(args.warmup)[0], S, stats=True)
     st_algo = mod.stats(reset=True)
     accum.zero_()
     torch.cuda.synchronize()   # zero_() runs on torch's stream, the module renders on its own
@@ -127,7 +172,7 @@ def main():
     # ---- warmup
     step = 0
     for _ in range(args.warmup):
-        mod.render(*sharding.step_sample_range(rank, world, step, S))
+        mod.render(*step_range(step))
         step += 1
     mod.synchronize()
     if world > 1:
@@ -135,13 +180,13 @@ def main():
     accum.zero_()
     torch.cuda.synchronize()
     mod.stats(reset=True)
-    first_timed = step
+    first_timed = step_range(step)[0]
 
     # ---- timed region: exactly K steps + the exchange step + device-side resolve
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        mod.render(*sharding.step_sample_range(rank, world, step, S))
+        mod.render(*step_range(step))
         step += 1
     mod.synchronize()
     sharding.reduce_accum_to_root(accum, dist if world > 1 else None)
@@ -173,15 +218,17 @@ def main():
         if args.save:
             np.save(args.save, img)
         kernel_ms = st["kernel_ms"] / max(1, st["launches"])
-        flops_launch = algorithmic_flops(st_algo)
+        # the instrumented launch traced S spp; the timed launches average my_count / K spp (204.8 at the defaults)
+        launch_scale = 1.0 if weak else (my_count / args.steps) / S
+        flops_launch = algorithmic_flops(st_algo) * launch_scale
         bvh = mod.bvh_info()
-        bytes_launch = algorithmic_bytes(st_algo, bvh["node_bytes"] / max(1, bvh["node_count"]))
+        bytes_launch = algorithmic_bytes(st_algo, bvh["node_bytes"] / max(1, bvh["node_count"])) * launch_scale
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"{args.scene}_{W}x{H}_{S}spp")
+                traffic = json.load(open(pmc)).get(f"{args.scene}_{W}x{H}_{S}spp")   # PMC bytes of one launch of this size, or None
             except Exception:
                 traffic = None
         out = {
@@ -191,17 +238,21 @@ def main():
             "mrays_per_s": total_rays / dt / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene}.scn {W}x{H}, {S} spp per step per GPU, {scene.tri_count} triangles, "
-                                   f"max 5 bounces + Russian roulette, seed 0xABCDEF (BASELINE.json configs[3])",
-                       "spp_per_step": S, "total_spp": S * args.steps * world, "first_sample_index": first_timed * world * S,
+            "config": {"workload": (f"{args.scene}.scn {W}x{H}, {scene.tri_count} triangles, max 5 bounces + Russian roulette, seed 0xABCDEF "
+                                    f"(BASELINE.json configs[3]); " +
+                                    (f"weak form: {S} spp per step per GPU" if weak else
+                                     f"{args.total_spp} spp in all, sample-partitioned over {world} GPU(s) ([g*S/G,(g+1)*S/G)), "
+                                     f"each share traced in {args.steps} steps of {my_count // args.steps}-{S} spp")),
+                       "spp_per_step": S, "total_spp": int(round(total_samples / (W * H))), "first_sample_index": first_timed,
                        "parallelism": f"sample-index sharding x{world}, one sum-reduce to rank 0" + ("" if args.backend == "nccl" else " (gloo REHEARSAL, not a measurement)"),
                        "pipeline": "megakernel" if not args.pipeline else "wavefront",
                        "bvh": bvh, "rays_per_sample": total_rays / total_samples},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "k_megakernel<false>" if not args.pipeline else "wavefront", "kernel_ms_avg": kernel_ms,
+                         "kernel": "k_megakernel<false, true>" if not args.pipeline else "wavefront", "kernel_ms_avg": kernel_ms,
+                         "spp_per_launch": S,
                          "flops_per_launch": flops_launch,
                          "per_ray": {"box_tests": st_algo["box_tests"] / st_algo["rays"], "tri_tests": st_algo["tri_tests"] / st_algo["rays"],
                                      "hit_frac": st_algo["hits"] / st_algo["rays"], "tex_fetches": st_algo["tex_fetches"] / st_algo["rays"]},
@@ -215,6 +266,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scene, W, H)
+            if args.psnr_spp > 0:
+                out["psnr_vs_cpu_ref_db"] = psnr_vs_oracle(mod, scene, args.psnr_spp)
+                out["psnr_note"] = (f"sRGB-encoded, clamped to [0,1], peak 1; GPU module vs CPU oracle, both at samples [0,{args.psnr_spp}) "
+                                    f"of the same workload, outside the timed region")
         print(json.dumps(out), flush=True)
 
     mod.bind_accum_buffer(None, 0)
