@@ -80,6 +80,18 @@ int tsc_decode_jpeg_file(const char* path, uint32_t* w_out, uint32_t* h_out, uin
 int tsc_decode_hdr_file(const char* path, uint32_t* w_out, uint32_t* h_out, float** rgba_out);
 void tsc_free_pixels(void* p);
 
+/* The OBJ reader on its own (tests, tools): what tinyobj::LoadObj returns to Scene::Init (src/scene.cpp:471-476) --
+ * attrib.vertices / texcoords / normals and, per shape, the triangulated corners as (vertex_index, texcoord_index,
+ * normal_index) with -1 for "absent" -- so that it can be compared with the real tiny_obj_loader's output
+ * (tests/golden/ref_obj_*.npz). Every *_out may be NULL; buffers are malloc'ed, release with tsc_free_pixels.
+ * corners_out holds counts->corners x 3 int32, the shapes one after the other (shape_sizes_out: corners per shape). */
+typedef struct tsc_obj_counts {
+    uint32_t v_floats, vt_floats, vn_floats;   /* array lengths in floats (3, 2, 3 per element) */
+    uint32_t shapes, corners;
+} tsc_obj_counts;
+int tsc_parse_obj_file(const char* path, tsc_obj_counts* counts, float** v_out, float** vt_out, float** vn_out,
+                       int32_t** shape_sizes_out, int32_t** corners_out);
+
 /* Stress variant of a scene ("4x / 16x midpoint-subdivided dragon"): every
  * mesh with at least min_triangles triangles has each triangle split into four at its edge
  * midpoints, `levels` times. Shared edges share the new vertex; attributes are averaged; the surface

@@ -49,6 +49,7 @@ def test_damaged_files_under_asan_ubsan(fuzz_binary, tmp_path, scene):
     assert "decoded" in r.stdout
     counts = [int(x) for x in r.stdout.replace(",", " ").split() if x.isdigit()]
     assert counts[0] > 0 and counts[1] > 0 and counts[2] > 0      # some files survive, some are refused, some scenes load
+    assert counts[3] > 0 and counts[4] >= 8                       # OBJ: well-formed ones parse, every bad-index case is refused
 
 
 @pytest.mark.parametrize("flags", [["-fsanitize=thread"], ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"]], ids=["tsan", "asan_ubsan"])

@@ -54,7 +54,11 @@ def test_shipped_textures_against_libjpeg(path):
     a, b = decode_jpeg(path), pil_rgba(path)
     assert a.shape == b.shape and (a[..., 3] == 255).all()
     d = np.abs(a.astype(int) - b.astype(int))
-    grey = (a[..., 0] == a[..., 1]).all() and (a[..., 1] == a[..., 2]).all() and "metal" in path or "roughness" in path
+    # (secondary cross-check against an independent decoder; the primary pin is bit-for-bit equality with the reference's
+    # own stb_image, tests/test_reference_pins.py) grey pictures have no chroma up-sampling or colour conversion to
+    # differ in: only the two IDCTs' rounding, 1 level
+    grey = bool((a[..., 0] == a[..., 1]).all() and (a[..., 1] == a[..., 2]).all())
+    assert grey == (("metal" in path) or ("roughness" in path))
     assert d.max() <= (1 if grey else 4)
     assert d.mean() <= 0.15
 

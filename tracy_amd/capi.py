@@ -61,6 +61,10 @@ class tsc_camera(C.Structure):
                 ("ratio", C.c_float), ("view", C.c_float * 16), ("projection", C.c_float * 16), ("inv_view_proj", C.c_float * 16)]
 
 
+class tsc_obj_counts(C.Structure):
+    _fields_ = [("v_floats", C.c_uint32), ("vt_floats", C.c_uint32), ("vn_floats", C.c_uint32), ("shapes", C.c_uint32), ("corners", C.c_uint32)]
+
+
 class tsc_texture_info(C.Structure):
     _fields_ = [("path", C.c_char_p), ("srgb", C.c_int), ("is_hdr", C.c_int), ("width", C.c_uint32), ("height", C.c_uint32)]
 
@@ -83,6 +87,8 @@ SCENE_SYMBOLS = {
     "tsc_decode_jpeg_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8))]),
     "tsc_decode_hdr_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]),
     "tsc_free_pixels": (None, [C.c_void_p]),
+    "tsc_parse_obj_file": (C.c_int, [C.c_char_p, C.POINTER(tsc_obj_counts), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
+                                     C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]),
     "tsc_subdivide": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "tsc_fill_desc": (C.c_int, [C.c_void_p, C.POINTER(trh_scene_desc)]),
 }

@@ -14,9 +14,10 @@
 //   * Radiance RGBE *.hdr ("#?RADIANCE" / "#?RGBE", FORMAT=32-bit_rle_rgbe, "-Y h +X w"), flat and
 //     new-style run-length scanlines; texel = mantissa * 2^(e - 136), alpha 1.
 //
-// PARITY UNPINNED against stb_image itself: the reference ships no decoded-pixel fixtures and its
-// binary cannot be built here. tests/test_image_decode.py pins these decoders against
-// libjpeg-turbo (through PIL) within a stated tolerance and against hand-made RGBE files exactly.
+// PINNED against stb_image itself: oracle/ref_dump.cpp runs the reference's own ext/stb_image.h (build container
+// only) and tests/test_reference_pins.py compares these decoders with its output BIT FOR BIT on every JPEG the
+// reference ships and on two Radiance files (fixtures tests/golden/ref_stb_*.npz). tests/test_image_decode.py keeps
+// the independent cross-check against libjpeg-turbo (through PIL) within a stated tolerance.
 #include "image_decode.h"
 
 #include <cmath>
@@ -124,13 +125,19 @@ inline int extend(int v, int nbits) {   // T.81 F.2.2.1
 
 inline uint8_t clamp_u8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
-// One 1-D pass of the Loeffler-Ligtenberg-Moschytz inverse DCT, constants in 12-bit fixed point
+// One 1-D pass of the Loeffler-Ligtenberg-Moschytz inverse DCT, constants in 12-bit fixed point.
+// The pictures must come out with stb_image's bits (the reference's textures are what stb decodes), so this pass and
+// idct_block follow stb's scalar arithmetic (STBI__IDCT_1D / stbi__idct_block, ext/stb_image.h -- public domain / MIT,
+// itself IJG's jidctint) term by term: same constants, same association, same rounding biases. That includes how the
+// constants are rounded: (int)(x * 4096 + 0.5) truncates toward zero, so the NEGATIVE constants end up one unit
+// closer to zero than -FIX(|x|) (e.g. -1.847759065 -> -7567, not -7568). tests/test_reference_pins.py holds the
+// bit-for-bit comparison with stb_image on every JPEG the reference ships.
 #define IMGDEC_FIX(x) ((int)((x) * 4096 + 0.5))
 struct Idct1D { int x0, x1, x2, x3, t0, t1, t2, t3; };
 inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
     Idct1D r;
     int p1 = (s2 + s6) * IMGDEC_FIX(0.5411961f);
-    int t2 = p1 + s6 * (-IMGDEC_FIX(1.847759065f));
+    int t2 = p1 + s6 * IMGDEC_FIX(-1.847759065f);
     int t3 = p1 + s2 * IMGDEC_FIX(0.765366865f);
     int t0 = (s0 + s4) * 4096;
     int t1 = (s0 - s4) * 4096;
@@ -144,10 +151,10 @@ inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, in
     t1 = t1 * IMGDEC_FIX(2.053119869f);
     t2 = t2 * IMGDEC_FIX(3.072711026f);
     t3 = t3 * IMGDEC_FIX(1.501321110f);
-    p1 = p5 + p1 * (-IMGDEC_FIX(0.899976223f));
-    p2 = p5 + p2 * (-IMGDEC_FIX(2.562915447f));
-    p3 = p3 * (-IMGDEC_FIX(1.961570560f));
-    p4 = p4 * (-IMGDEC_FIX(0.390180644f));
+    p1 = p5 + p1 * IMGDEC_FIX(-0.899976223f);
+    p2 = p5 + p2 * IMGDEC_FIX(-2.562915447f);
+    p3 = p3 * IMGDEC_FIX(-1.961570560f);
+    p4 = p4 * IMGDEC_FIX(-0.390180644f);
     r.t3 = t3 + p1 + p4; r.t2 = t2 + p2 + p3; r.t1 = t1 + p2 + p4; r.t0 = t0 + p1 + p3;
     return r;
 }
@@ -276,8 +283,9 @@ bool decode_scan(Jpeg& j, const int* order, int n_in_scan, const uint8_t*& p, co
 
 // ---- chroma up-sampling: one output row of `w_out` samples from the component's rows
 // "triangle" filter: every output sample is 3/4 the nearer input sample + 1/4 the farther one
-void upsample_row(uint8_t* out, const Component& c, int hs, int vs, int y_out, int w_out, std::vector<int>& tmp) {
-    const int rows = c.h2;
+// `rows` = the component's rows that belong to the picture, ceil(height * v / vmax): the rows below them in the plane
+// are MCU padding and never take part (stb_image advances its second line only while ypos < img_comp.y).
+void upsample_row(uint8_t* out, const Component& c, int hs, int vs, int y_out, int w_out, int rows, std::vector<int>& tmp) {
     const int w_in = (w_out + hs - 1) / hs;
     const int y_in = y_out / vs;
     const uint8_t* near = &c.plane[(size_t)std::min(y_in, rows - 1) * c.w2];
@@ -285,7 +293,7 @@ void upsample_row(uint8_t* out, const Component& c, int hs, int vs, int y_out, i
     if (vs == 2 && hs <= 2) {
         const bool lower = (y_out & 1) != 0;                 // odd output rows lean on the next input row
         int yf = lower ? y_in + 1 : y_in - 1;
-        yf = std::max(0, std::min(yf, std::min(rows, (c.h2)) - 1));
+        yf = std::max(0, std::min(yf, std::min(rows, c.h2) - 1));
         const uint8_t* far = &c.plane[(size_t)yf * c.w2];
         if (hs == 1) {
             for (int i = 0; i < w_out; ++i) out[i] = (uint8_t)((3 * near[i] + far[i] + 2) >> 2);
@@ -443,7 +451,8 @@ bool decode_jpeg(const uint8_t* data, size_t size, Image8& img, std::string& err
     const bool is_rgb = j.ncomp == 3 && (adobe_transform == 0 || (!j.jfif && adobe_transform < 0 && j.comp[0].id == 'R' && j.comp[1].id == 'G' && j.comp[2].id == 'B'));
     for (int i = 0; i < j.ncomp; ++i) rows[i].resize((size_t)j.width + 16);
     for (int y = 0; y < j.height; ++y) {
-        for (int i = 0; i < j.ncomp; ++i) upsample_row(rows[i].data(), j.comp[i], j.hmax / j.comp[i].h, j.vmax / j.comp[i].v, y, j.width, tmp);
+        for (int i = 0; i < j.ncomp; ++i) upsample_row(rows[i].data(), j.comp[i], j.hmax / j.comp[i].h, j.vmax / j.comp[i].v, y, j.width,
+                                                         (j.height * j.comp[i].v + j.vmax - 1) / j.vmax, tmp);
         uint8_t* o = &img.rgba[(size_t)y * j.width * 4];
         if (j.ncomp == 1) {
             for (int x = 0; x < j.width; ++x) { o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = rows[0][x]; o[4 * x + 3] = 255; }

@@ -9,9 +9,11 @@
 #include "tracy_scene.h"
 #include "hmath.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <limits>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -240,9 +242,20 @@ Mesh& add_mesh(tsc_scene& s, Mesh&& mesh, const mat4& transform, bool compute_no
 }
 
 // ---------------------------------------------------------------------------------------
-// Wavefront OBJ reader with the behaviour of tinyobj::LoadObj as Scene::Init uses it
-// (src/scene.cpp:471-527): triangulate=true (fan), shapes split on 'o'/'g', per-corner
-// v/vt/vn indices, negative (relative) indices, missing vt/vn -> -1.
+// Wavefront OBJ reader with the behaviour of tinyobj::LoadObj as Scene::Init uses it (src/scene.cpp:471-527;
+// ext/tiny_obj_loader.h 2.0.0, default arguments: triangulate = true, real_t = float). What decides hit ids is
+// restated, and pinned against the real tiny_obj_loader by tests/golden/ref_obj_*.npz (oracle/ref_dump.cpp):
+//   * numbers: tinyobj's own decimal parser (tiny_obj_loader.h:865-1003), not strtod -- the integer digits are
+//     accumulated as m = 10 m + d, fraction digits added as d * 10^-k (a table for k < 8, pow beyond), a decimal
+//     exponent applied as ldexp(m * 5^e, e), all in double, then one rounding to float;
+//   * corners "v", "v/vt", "v//vn", "v/vt/vn" with atoi semantics, index 0 invalid, negative = relative to the
+//     counts at that line (:799-820, :1145-1200);
+//   * faces: a triangle as it is; a QUAD split along its SHORTER diagonal ([0,1,2][0,2,3] if |v2-v0|^2 < |v3-v1|^2,
+//     else [0,1,3][1,2,3], :1457-1565); five and more corners by tinyobj's ear clipping in the plane of the first
+//     non-degenerate corner (:1566-1852);
+//   * shapes split at 'g' and 'o' lines, shapes without faces dropped (:2813-2888, :3007-3016).
+// Deviation, on purpose: a corner whose index lies outside the arrays read so far makes the load FAIL with a message;
+// tinyobj lets such triangles through (a warning at most) and Scene::Init then reads attrib.vertices out of bounds.
 // ---------------------------------------------------------------------------------------
 struct ObjIndex { int v, vt, vn; };
 struct ObjShape { std::vector<ObjIndex> idx; };
@@ -251,82 +264,252 @@ struct ObjData {
     std::vector<ObjShape> shapes;
 };
 
-bool parse_obj_index(const char*& p, int nv, int nvt, int nvn, ObjIndex& out) {
-    auto fix = [](int i, int n) { return i > 0 ? i - 1 : (i < 0 ? n + i : -1); };
-    out = {-1, -1, -1};
-    char* e;
-    long vi = strtol(p, &e, 10);
-    if (e == p) return false;
-    out.v = fix((int)vi, nv);
-    p = e;
-    if (*p != '/') return true;
-    ++p;
-    if (*p == '/') {  // v//vn
-        ++p;
-        long ni = strtol(p, &e, 10);
-        out.vn = fix((int)ni, nvn);
-        p = e;
-        return true;
+inline bool obj_is_space(char c) { return c == ' ' || c == '\t'; }
+inline bool obj_is_digit(char c) { return c >= '0' && c <= '9'; }
+inline bool obj_is_newline(char c) { return c == '\r' || c == '\n' || c == '\0'; }
+
+// tryParseDouble (tiny_obj_loader.h:865-1003) on [s, s_end): false leaves *result alone
+bool obj_parse_double(const char* s, const char* s_end, double* result) {
+    if (s >= s_end) return false;
+    double mantissa = 0.0;
+    int exponent = 0;
+    bool negative = false, exp_negative = false, leading_dot = false;
+    const char* c = s;
+    int read = 0;
+    if (*c == '+' || *c == '-') {
+        negative = *c == '-';
+        ++c;
+        if (c != s_end && *c == '.') leading_dot = true;
+    } else if (*c == '.') {
+        leading_dot = true;
+    } else if (!obj_is_digit(*c)) {
+        return false;
     }
-    long ti = strtol(p, &e, 10);
-    out.vt = fix((int)ti, nvt);
-    p = e;
-    if (*p != '/') return true;
-    ++p;
-    long ni = strtol(p, &e, 10);
-    out.vn = fix((int)ni, nvn);
-    p = e;
+    if (!leading_dot) {
+        while (c != s_end && obj_is_digit(*c)) {
+            mantissa = mantissa * 10 + (*c - '0');
+            ++c;
+            ++read;
+        }
+        if (read == 0) return false;
+    }
+    bool has_exponent = false;
+    if (c != s_end) {
+        if (*c == '.') {
+            static const double kPow10[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+            ++c;
+            read = 1;
+            while (c != s_end && obj_is_digit(*c)) {
+                mantissa += (*c - '0') * (read < 8 ? kPow10[read] : std::pow(10.0, -read));
+                ++read;
+                ++c;
+            }
+            has_exponent = c != s_end && (*c == 'e' || *c == 'E');
+        } else if (*c == 'e' || *c == 'E') {
+            has_exponent = true;
+        }
+    }
+    if (has_exponent) {
+        ++c;
+        if (c != s_end && (*c == '+' || *c == '-')) {
+            exp_negative = *c == '-';
+            ++c;
+        } else if (!obj_is_digit(*c)) {
+            return false;   // an empty exponent is not a number
+        }
+        read = 0;
+        while (c != s_end && obj_is_digit(*c)) {
+            if (exponent > 2147483647 / 10) return false;
+            exponent = exponent * 10 + (*c - '0');
+            ++c;
+            ++read;
+        }
+        if (exp_negative) exponent = -exponent;
+        if (read == 0) return false;
+    }
+    *result = (negative ? -1 : 1) * (exponent ? std::ldexp(mantissa * std::pow(5.0, exponent), exponent) : mantissa);
     return true;
 }
 
-bool load_obj(const std::string& path, ObjData& out) {
-    FILE* fp = fopen(path.c_str(), "rb");
-    if (!fp) return false;
-    std::vector<char> linebuf(1 << 16);
-    ObjShape cur;
-    auto flush = [&]() {
-        if (!cur.idx.empty()) {
-            out.shapes.push_back(std::move(cur));
-            cur = ObjShape{};
+// parseReal (tiny_obj_loader.h:1004-1012): a token that is no number is 0
+float obj_parse_real(const char*& token) {
+    token += strspn(token, " \t");
+    const char* end = token + strcspn(token, " \t\r");
+    double val = 0.0;
+    (void)obj_parse_double(token, end, &val);
+    token = end;
+    return static_cast<float>(val);
+}
+
+// fixIndex (tiny_obj_loader.h:799-820)
+bool obj_fix_index(int idx, int n, int* out) {
+    if (idx > 0) { *out = idx - 1; return true; }
+    if (idx == 0) return false;
+    *out = n + idx;
+    return true;
+}
+
+// parseTriple (tiny_obj_loader.h:1145-1200)
+bool parse_obj_index(const char*& p, int nv, int nvt, int nvn, ObjIndex& out) {
+    out = {-1, -1, -1};
+    if (!obj_fix_index(atoi(p), nv, &out.v)) return false;
+    p += strcspn(p, "/ \t\r");
+    if (*p != '/') return true;
+    ++p;
+    if (*p == '/') {   // v//vn
+        ++p;
+        if (!obj_fix_index(atoi(p), nvn, &out.vn)) return false;
+        p += strcspn(p, "/ \t\r");
+        return true;
+    }
+    if (!obj_fix_index(atoi(p), nvt, &out.vt)) return false;   // v/vt or v/vt/vn
+    p += strcspn(p, "/ \t\r");
+    if (*p != '/') return true;
+    ++p;
+    if (!obj_fix_index(atoi(p), nvn, &out.vn)) return false;
+    p += strcspn(p, "/ \t\r");
+    return true;
+}
+
+// pnpoly as tinyobj uses it on a triangle (tiny_obj_loader.h:1414-1427)
+bool obj_point_in_triangle(const float* vx, const float* vy, float tx, float ty) {
+    bool inside = false;
+    for (int i = 0, j = 2; i < 3; j = i++)
+        if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) inside = !inside;
+    return inside;
+}
+
+// exportGroupsToShape's triangulation of one face (tiny_obj_loader.h:1446-1855). `v` = the positions read so far.
+void obj_triangulate(const std::vector<ObjIndex>& face, const std::vector<float>& v, std::vector<ObjIndex>& out) {
+    size_t n = face.size();
+    if (n < 3) return;   // "Degenerated face found"
+    auto pos = [&](const ObjIndex& ix, int a) { return v[(size_t)ix.v * 3 + a]; };
+    if (n == 4) {
+        float d02 = 0.f, d13 = 0.f;
+        float e02[3], e13[3];
+        for (int a = 0; a < 3; ++a) {
+            e02[a] = pos(face[2], a) - pos(face[0], a);
+            e13[a] = pos(face[3], a) - pos(face[1], a);
         }
+        d02 = e02[0] * e02[0] + e02[1] * e02[1] + e02[2] * e02[2];
+        d13 = e13[0] * e13[0] + e13[1] * e13[1] + e13[2] * e13[2];
+        if (d02 < d13) out.insert(out.end(), {face[0], face[1], face[2], face[0], face[2], face[3]});
+        else out.insert(out.end(), {face[0], face[1], face[3], face[1], face[2], face[3]});
+        return;
+    }
+    // the two axes of the projection plane: those of the first corner whose edges are not parallel
+    size_t axes[2] = {1, 2};
+    for (size_t k = 0; k < n; ++k) {
+        const ObjIndex &i0 = face[k % n], &i1 = face[(k + 1) % n], &i2 = face[(k + 2) % n];
+        const float e0x = pos(i1, 0) - pos(i0, 0), e0y = pos(i1, 1) - pos(i0, 1), e0z = pos(i1, 2) - pos(i0, 2);
+        const float e1x = pos(i2, 0) - pos(i1, 0), e1y = pos(i2, 1) - pos(i1, 1), e1z = pos(i2, 2) - pos(i1, 2);
+        const float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
+        const float eps = std::numeric_limits<float>::epsilon();
+        if (cx > eps || cy > eps || cz > eps) {
+            if (!(cx > cy && cx > cz)) {
+                axes[0] = 0;
+                if (cz > cx && cz > cy) axes[1] = 1;
+            }
+            break;
+        }
+    }
+    std::vector<ObjIndex> rest = face;
+    size_t guess = 0, iterations_left = face.size(), previous = rest.size();
+    while (rest.size() > 3 && iterations_left > 0) {
+        n = rest.size();
+        if (guess >= n) guess -= n;
+        if (previous != n) { previous = n; iterations_left = n; } else { --iterations_left; }
+        ObjIndex ind[3];
+        float vx[3], vy[3];
+        for (size_t k = 0; k < 3; ++k) {
+            ind[k] = rest[(guess + k) % n];
+            vx[k] = pos(ind[k], (int)axes[0]);
+            vy[k] = pos(ind[k], (int)axes[1]);
+        }
+        const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+        const float cross = e0x * e1y - e0y * e1x;
+        const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+        if (cross * area < 0.f) { ++guess; continue; }   // "an internal angle"
+        bool overlap = false;
+        for (size_t other = 3; other < n; ++other) {
+            const size_t idx = (guess + other) % n;
+            if (obj_point_in_triangle(vx, vy, pos(rest[idx], (int)axes[0]), pos(rest[idx], (int)axes[1]))) { overlap = true; break; }
+        }
+        if (overlap) { ++guess; continue; }
+        out.insert(out.end(), {ind[0], ind[1], ind[2]});   // an ear: clip its middle corner
+        rest.erase(rest.begin() + (long)((guess + 1) % n));
+    }
+    if (rest.size() == 3) out.insert(out.end(), {rest[0], rest[1], rest[2]});
+}
+
+bool load_obj(const std::string& path, ObjData& out, std::string& err) {
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) { err = "cannot open " + path; return false; }
+    std::string text;
+    {
+        char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), fp)) > 0) text.append(buf, got);
+    }
+    fclose(fp);
+    ObjShape cur;
+    std::vector<std::vector<ObjIndex>> faces;   // the open face group (triangulated when the shape is flushed)
+    auto export_faces = [&]() {
+        for (const auto& f : faces) obj_triangulate(f, out.v, cur.idx);
+        faces.clear();
     };
-    while (fgets(linebuf.data(), (int)linebuf.size(), fp)) {
-        const char* p = linebuf.data();
-        while (*p == ' ' || *p == '\t') ++p;
-        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
-            char* e;
+    auto flush = [&]() {
+        export_faces();
+        if (!cur.idx.empty()) out.shapes.push_back(std::move(cur));
+        cur = ObjShape{};
+    };
+    size_t line_no = 0;
+    for (size_t at = 0; at < text.size();) {
+        size_t eol = text.find('\n', at);
+        if (eol == std::string::npos) eol = text.size();
+        std::string line = text.substr(at, eol - at);
+        at = eol + 1;
+        ++line_no;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        const char* p = line.c_str();
+        p += strspn(p, " \t");
+        if (*p == '\0' || *p == '#') continue;
+        if (p[0] == 'v' && obj_is_space(p[1])) {
             p += 2;
-            for (int k = 0; k < 3; ++k) { out.v.push_back(static_cast<float>(strtod(p, &e))); p = e; }
-        } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
-            char* e;
+            for (int k = 0; k < 3; ++k) out.v.push_back(obj_parse_real(p));
+        } else if (p[0] == 'v' && p[1] == 'n' && obj_is_space(p[2])) {
             p += 3;
-            for (int k = 0; k < 3; ++k) { out.vn.push_back(static_cast<float>(strtod(p, &e))); p = e; }
-        } else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) {
-            char* e;
+            for (int k = 0; k < 3; ++k) out.vn.push_back(obj_parse_real(p));
+        } else if (p[0] == 'v' && p[1] == 't' && obj_is_space(p[2])) {
             p += 3;
-            for (int k = 0; k < 2; ++k) { out.vt.push_back(static_cast<float>(strtod(p, &e))); p = e; }
-        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            for (int k = 0; k < 2; ++k) out.vt.push_back(obj_parse_real(p));
+        } else if (p[0] == 'f' && obj_is_space(p[1])) {
             p += 2;
+            p += strspn(p, " \t");
             std::vector<ObjIndex> face;
             const int nv = (int)out.v.size() / 3, nvt = (int)out.vt.size() / 2, nvn = (int)out.vn.size() / 3;
-            for (;;) {
-                while (*p == ' ' || *p == '\t') ++p;
-                if (*p == '\0' || *p == '\n' || *p == '\r') break;
+            while (!obj_is_newline(*p)) {
                 ObjIndex ix;
-                if (!parse_obj_index(p, nv, nvt, nvn, ix)) break;
+                if (!parse_obj_index(p, nv, nvt, nvn, ix)) {   // tinyobj: LoadObj fails ("zero value for face index")
+                    err = path + ": line " + std::to_string(line_no) + ": not a face corner (index 0 or no number)";
+                    return false;
+                }
+                if (ix.v < 0 || ix.v >= nv || ix.vt < -1 || ix.vt >= nvt || ix.vn < -1 || ix.vn >= nvn) {
+                    err = path + ": line " + std::to_string(line_no) + ": face corner index outside the " + std::to_string(nv) + " positions / " +
+                          std::to_string(nvt) + " texture coordinates / " + std::to_string(nvn) + " normals read so far";
+                    return false;
+                }
                 face.push_back(ix);
+                p += strspn(p, " \t\r");
             }
-            for (size_t k = 2; k < face.size(); ++k) {  // fan triangulation
-                cur.idx.push_back(face[0]);
-                cur.idx.push_back(face[k - 1]);
-                cur.idx.push_back(face[k]);
-            }
-        } else if ((p[0] == 'o' || p[0] == 'g') && (p[1] == ' ' || p[1] == '\t' || p[1] == '\n' || p[1] == '\r')) {
+            faces.push_back(std::move(face));
+        } else if (strncmp(p, "usemtl", 6) == 0) {
+            export_faces();   // a material change closes the face group but not the shape (tiny_obj_loader.h:2747-2755)
+        } else if ((p[0] == 'g' || p[0] == 'o') && obj_is_space(p[1])) {
             flush();
         }
     }
     flush();
-    fclose(fp);
     return true;
 }
 
@@ -480,8 +663,9 @@ tsc_scene* tsc_load(const char* scn_path, const char* asset_root, int override_w
             if (sscanf(params, "%259s %259s (%f, %f, %f) (%f, %f, %f) %f", file_name, mat_name, &tr.x, &tr.y, &tr.z, &rot.x, &rot.y,
                        &rot.z, &scaling) >= 2) {
                 ObjData obj;
-                if (!load_obj(join_path(root, file_name), obj)) {
-                    set_err(std::string("tsc_load: cannot read OBJ ") + join_path(root, file_name));
+                std::string obj_err;
+                if (!load_obj(join_path(root, file_name), obj, obj_err)) {
+                    set_err("tsc_load: cannot read OBJ: " + obj_err);
                     fclose(fp);
                     delete s;
                     return nullptr;
@@ -741,6 +925,41 @@ int tsc_decode_hdr_file(const char* path, uint32_t* w_out, uint32_t* h_out, floa
 }
 
 void tsc_free_pixels(void* p) { free(p); }
+
+int tsc_parse_obj_file(const char* path, tsc_obj_counts* counts, float** v_out, float** vt_out, float** vn_out, int32_t** shape_sizes_out, int32_t** corners_out) {
+    if (!path || !counts) { set_err("tsc_parse_obj_file: NULL argument"); return TRH_ERR_INVALID_ARG; }
+    ObjData obj;
+    std::string err;
+    if (!load_obj(path, obj, err)) { set_err("tsc_parse_obj_file: " + err); return TRH_ERR_INVALID_ARG; }
+    size_t corners = 0;
+    for (const ObjShape& sh : obj.shapes) corners += sh.idx.size();
+    counts->v_floats = (uint32_t)obj.v.size();
+    counts->vt_floats = (uint32_t)obj.vt.size();
+    counts->vn_floats = (uint32_t)obj.vn.size();
+    counts->shapes = (uint32_t)obj.shapes.size();
+    counts->corners = (uint32_t)corners;
+    auto dup = [](const void* src, size_t bytes) -> void* {
+        void* p = malloc(bytes ? bytes : 1);
+        if (p && bytes) memcpy(p, src, bytes);
+        return p;
+    };
+    if (v_out) *v_out = (float*)dup(obj.v.data(), obj.v.size() * 4);
+    if (vt_out) *vt_out = (float*)dup(obj.vt.data(), obj.vt.size() * 4);
+    if (vn_out) *vn_out = (float*)dup(obj.vn.data(), obj.vn.size() * 4);
+    if (shape_sizes_out) {
+        std::vector<int32_t> sizes;
+        for (const ObjShape& sh : obj.shapes) sizes.push_back((int32_t)sh.idx.size());
+        *shape_sizes_out = (int32_t*)dup(sizes.data(), sizes.size() * 4);
+    }
+    if (corners_out) {
+        std::vector<int32_t> flat;
+        flat.reserve(corners * 3);
+        for (const ObjShape& sh : obj.shapes)
+            for (const ObjIndex& ix : sh.idx) { flat.push_back(ix.v); flat.push_back(ix.vt); flat.push_back(ix.vn); }
+        *corners_out = (int32_t*)dup(flat.data(), flat.size() * 4);
+    }
+    return TRH_OK;
+}
 
 int tsc_fill_desc(const tsc_scene* cs, trh_scene_desc* out) {
     if (!cs || !out) { set_err("tsc_fill_desc: NULL argument"); return TRH_ERR_INVALID_ARG; }
