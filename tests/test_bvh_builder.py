@@ -110,6 +110,10 @@ def test_invalid_descriptions_are_rejected():
     d, keep = make_desc([(0, 0, 0), (1, 0, 0), (0, 1, 0)], [0, 1, 7])   # vertex index out of range
     assert lib.trh_bvh_build_host(C.byref(d), None, None, C.byref(bad)) != 0
     assert b"out of range" in lib.trh_last_error()
+    for poison in (np.nan, np.inf, -np.inf):       # NaN / inf positions: TRH_ERR_INVALID_ARG, never into the builders
+        d, keep = make_desc([(0, 0, 0), (1, poison, 0), (0, 1, 0)], [0, 1, 2])
+        assert lib.trh_bvh_build_host(C.byref(d), None, None, C.byref(bad)) == 1
+        assert b"not finite" in lib.trh_last_error()
 
 
 def test_on_disk_cache(scene_loader, tmp_path):
@@ -165,6 +169,42 @@ def test_on_disk_cache(scene_loader, tmp_path):
             f.write(raw)
         info6, h6, bad6, _ = build_host(sc.desc)
         assert info6.from_cache == 0 and bad6 == 0 and h6 == h_plain, "a structurally wrong cache file was trusted"
+
+        def rewrite(mutate):
+            """damage the (rebuilt, sound) file, then make its checksum right again: only the structural check can refuse it"""
+            with open(path, "rb") as f:
+                raw = bytearray(f.read())
+            mutate(raw, int.from_bytes(raw[16:24], "little"), int.from_bytes(raw[24:32], "little"), int.from_bytes(raw[32:40], "little"))
+            hsh = 1469598103934665603
+            for byte in raw[96:]:
+                hsh = ((hsh ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            raw[88:96] = hsh.to_bytes(8, "little")
+            with open(path, "wb") as f:
+                f.write(raw)
+            info, h, bad, why = build_host(sc.desc)
+            assert info.from_cache == 0 and bad == 0 and h == h_plain, "a damaged cache file with a valid checksum was trusted"
+            assert build_host(sc.desc)[0].from_cache == 1      # ... and the rewritten file is sound again
+
+        def bad_prim_index(raw, n_nodes_f32, n_nodes16, n_tris_f32):   # a leaf-order entry far outside the triangle array
+            at = 96 + (n_nodes_f32 + n_nodes16 + n_tris_f32) * 4 + 4 * 1000
+            raw[at:at + 4] = (0x7FFFFF00).to_bytes(4, "little")
+
+        def zero_scale(raw, *_):                     # header scalar: frame_scale = 0 -> 1 / scale = inf in the kernels
+            raw[60:64] = np.float32(0.0).tobytes()
+
+        def nan_centre(raw, *_):
+            raw[48:52] = np.float32(np.nan).tobytes()
+
+        def odd_scale(raw, *_):                      # not a power of two
+            raw[60:64] = (np.frombuffer(bytes(raw[60:64]), np.float32) * np.float32(1.5)).tobytes()
+
+        def moved_triangle(raw, n_nodes_f32, n_nodes16, n_tris_f32):   # right id, wrong geometry: v0.x of record 5 nudged inside its leaf box
+            at = 96 + (n_nodes_f32 + n_nodes16) * 4 + 5 * 48
+            x = np.frombuffer(bytes(raw[at:at + 4]), np.float32)
+            raw[at:at + 4] = np.nextafter(x, np.float32(np.inf)).astype(np.float32).tobytes()
+
+        for m in (bad_prim_index, zero_scale, nan_centre, odd_scale, moved_triangle):
+            rewrite(m)
     finally:
         lib.trh_set_bvh_cache_dir(None)
     assert build_host(sc.desc)[0].from_cache == 0

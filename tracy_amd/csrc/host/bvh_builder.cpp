@@ -463,6 +463,12 @@ bool cache_load(const std::string& path, uint64_t key, size_t n_tris, Result& ou
     // sizes must be what a tree over n_tris triangles can have, before anything is allocated from them
     ok = ok && h.n_prims == n_tris && h.n_tris_f32 == (uint64_t)n_tris * 12 && h.n_nodes_f32 % 16 == 0 && h.n_nodes16 * 2 == h.n_nodes_f32 &&
          h.n_nodes_f32 / 16 >= 1 && h.n_nodes_f32 / 16 <= std::max<uint64_t>(n_tris, 1) && h.max_depth <= (uint32_t)kMaxDepth;
+    // header scalars that reach the kernels: the frame scale must be a finite positive power of two, the centre finite
+    {
+        int e = 0;
+        ok = ok && std::isfinite(h.frame_scale) && h.frame_scale > 0.f && std::frexp(h.frame_scale, &e) == 0.5f && std::isfinite(h.frame_center[0]) &&
+             std::isfinite(h.frame_center[1]) && std::isfinite(h.frame_center[2]) && std::isfinite(h.fp16_inflation) && std::isfinite(h.sah_cost);
+    }
     if (ok) {
         out = Result{};
         out.nodes.resize(h.n_nodes_f32);
@@ -535,14 +541,25 @@ uint64_t validate(const std::vector<InputTriangle>& tris, const Result& r, std::
     uint64_t bad = 0;
     auto fail = [&](const std::string& what) { if (bad++ == 0) first = what; };
     const size_t n_nodes = r.nodes.size() / 16, n_prims = r.prim_index.size();
-    if (r.nodes16.size() != n_nodes * 8) fail("nodes16 size");
-    if (r.tris.size() != n_prims * 12 || n_prims != tris.size()) fail("triangle array size");
+    // This check is also the gate between an on-disk cache file and the GPU (build_cached), so it must be memory-safe
+    // on ANY input: wrong array sizes or a permutation entry out of range end it at once -- everything below indexes
+    // the arrays through those.
+    if (r.nodes.size() % 16 != 0) { fail("node array size"); return bad; }
+    if (r.nodes16.size() != n_nodes * 8) { fail("nodes16 size"); return bad; }
+    if (r.tris.size() != n_prims * 12 || n_prims != tris.size()) { fail("triangle array size"); return bad; }
     std::vector<uint8_t> seen_prim(tris.size(), 0), seen_leaf_pos(n_prims, 0), seen_node(n_nodes, 0);
     for (uint32_t p : r.prim_index) {
-        if (p >= tris.size()) { fail("prim_index out of range"); continue; }
+        if (p >= tris.size()) { fail("prim_index out of range"); return bad; }
         if (seen_prim[p]++) fail("triangle stored twice");
     }
     for (size_t i = 0; i < tris.size(); ++i) if (!seen_prim[i]) { fail("triangle missing from the tree"); break; }
+    // the frame of the fp16 records: a finite centre and a finite positive power-of-two scale (the kernels divide by it)
+    {
+        int e = 0;
+        const bool scale_ok = std::isfinite(r.frame_scale) && r.frame_scale > 0.f && std::frexp(r.frame_scale, &e) == 0.5f;
+        const bool centre_ok = std::isfinite(r.frame_center[0]) && std::isfinite(r.frame_center[1]) && std::isfinite(r.frame_center[2]);
+        if (!scale_ok || !centre_ok) { fail("frame of the fp16 records is not finite / not a power of two"); return bad; }
+    }
     const double s = r.frame_scale;
     struct Item { int node; int depth; };
     std::vector<Item> todo;
@@ -588,9 +605,14 @@ uint64_t validate(const std::vector<InputTriangle>& tris, const Result& r, std::
                     for (const float* v : vs)
                         for (int a = 0; a < 3; ++a)
                             if (v[a] < f[fi[c][2 * a]] || v[a] > f[fi[c][2 * a + 1]]) fail("leaf box does not contain its triangle");
+                    const float* rec = &r.tris[pos * 12];
                     uint32_t id;
-                    memcpy(&id, &r.tris[pos * 12 + 3], 4);
+                    memcpy(&id, &rec[3], 4);
                     if (id != t.packed_id) fail("triangle record id mismatch");
+                    // the record must BE this triangle (a stale or foreign cache file with a matching key would otherwise
+                    // render other geometry without complaint): v0, v1 - v0, v2 - v0 exactly as the builders write them
+                    for (int a = 0; a < 3; ++a)
+                        if (rec[a] != t.v0[a] || rec[4 + a] != t.v1[a] - t.v0[a] || rec[8 + a] != t.v2[a] - t.v0[a]) { fail("triangle record geometry mismatch"); break; }
                 }
             }
         }
