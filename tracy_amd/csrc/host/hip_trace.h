@@ -19,7 +19,11 @@
 #include <type_traits>
 #include <vector>
 
-#include "../../../include/tracy_hip.h"
+#if __has_include("tracy_hip.h")
+#include "tracy_hip.h"                      // on the include path (inside Tracy: ext/tracy_hip/include, integration/tracy_hip.cmake)
+#else
+#include "../../../include/tracy_hip.h"     // this repository's layout
+#endif
 #include "tracy_module.h"
 
 namespace tracy_hip {
@@ -144,7 +148,12 @@ bool FlattenCamera(const SceneT& scene, FlatScene& out) {
     return Invert4x4(pv, out.inv_view_proj);
 }
 
+#if defined(TRACY_HIP_USE_REFERENCE_MODULE_H)
+// inside Tracy: the four types are the reference's own (integration/hip_module.h names them), no stand-ins exist
+template <class SceneT, class Base, class WindowT, class EventT>
+#else
 template <class SceneT, class Base = TracyModuleT<SceneT>, class WindowT = WindowHandle, class EventT = TracyEvent>
+#endif
 class HipTraceT final : public Base {
 public:
     // ngpus: GPUs of the node to use (devices 0..ngpus-1, <= 0 = all of them); one host thread drives them through
