@@ -48,6 +48,11 @@
 #include <omp.h>
 #endif
 
+// TEST-ONLY switch (oref_set_matchance0): the floor of materialspecularchance, 0.1 in the reference (material.h:253).
+// Setting it to 0 removes the 10 % white specular lobe of non-metals -- the hypothesis DESIGN.md section 2 tests against
+// the reference's doc/dragon.jpg screenshot. Never touched by any other test or by the product.
+static float g_matchance_floor = .1f;
+
 namespace {
 
 using u32 = uint32_t;
@@ -563,7 +568,7 @@ void Scatter(const oref_scene& s, const trh_material& m, const Ray& ray, const H
         attenuation = basecolor;
     } else {  // BRDF
         const vec3 specularcolor = lerp(vec3(.85f), basecolor, metalness);
-        const float materialspecularchance = lerp(.1f, 1.f, metalness);
+        const float materialspecularchance = lerp(g_matchance_floor, 1.f, metalness);   // .1f in the reference (material.h:253)
         const float fresnelspecularchance = lerp(materialspecularchance, 1.f, (1.f - roughness) * schlick(-VdotN, 1.f));
         const bool is_specular = fastrand(rng) < fresnelspecularchance;
         scatteredDirection = is_specular ? specular : scattered;
@@ -676,6 +681,8 @@ void oref_set_camera(oref_scene* s, const float eye[3], const float inv_view_pro
     s->eye = vec3(eye[0], eye[1], eye[2]);
     memcpy(s->ivp, inv_view_proj, sizeof(s->ivp));
 }
+
+void oref_set_matchance0(int on) { g_matchance_floor = on ? 0.f : .1f; }
 
 void oref_set_debug_view(oref_scene* s, int view, const float view3x3[9]) {
     s->debug_view = (u32)view;

@@ -24,6 +24,8 @@ def lib():
         L.oref_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oref_reset.argtypes = [C.c_void_p]
         L.oref_set_debug_view.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oref_set_matchance0.argtypes = [C.c_int]
+        L.oref_set_matchance0.restype = None
         L.oref_tree_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.oref_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oref_sample_radiance.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
