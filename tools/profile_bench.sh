@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline $*"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --psnr-spp 0 $*"   # bench.py's default steps/warmup: the launch size the driver measures
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -5 $OUT/stats.log; exit 1; }
 i=0
 for PMC in "FETCH_SIZE TCC_HIT_sum" \

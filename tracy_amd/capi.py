@@ -166,7 +166,7 @@ def hip_lib():
     """Load libtracy_hip.so (hand-written HIP kernels + C ABI). No fallback of any kind."""
     global _hip_lib
     if _hip_lib is None:
-        path = os.path.join(LIB_DIR, "libtracy_hip.so")
+        path = os.environ.get("TRACY_HIP_LIBRARY") or os.path.join(LIB_DIR, "libtracy_hip.so")   # the override: A/B builds of the kernels
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension must be built (there is no CPU fallback)")
         _hip_lib = _bind(C.CDLL(path), HIP_SYMBOLS)

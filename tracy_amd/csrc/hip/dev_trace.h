@@ -247,7 +247,7 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
     if (STATS) { cnt.box_tests += 2; if (first_active_lane()) cnt.w_inner += 1; }
     const bool h0 = tmin0 <= tmax0;
     const bool h1 = tmin1 <= tmax1;
-    const bool swp = h1 && (!h0 || tmin1 < tmin0);   // child 1 is the nearer (or the only) hit
+    const bool swp = h1 & (!h0 | (tmin1 < tmin0));   // child 1 is the nearer (or the only) hit; bitwise: no short-circuit branch
     const int nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
     tv.top[TRH_BLOCK] = farc;   // unconditional: the row above the top is free; it only counts if both were hit
     const bool any = h0 || h1;

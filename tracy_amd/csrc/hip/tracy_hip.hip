@@ -156,8 +156,12 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, Re
 #ifndef TRH_INNER_REPEAT
 #define TRH_INNER_REPEAT 3
 #endif
+// Waves per SIMD the megakernel is compiled for. 5 (<= 96 VGPRs, 13 of them spilled to scratch inside shade()) against
+// 4 (119 VGPRs, no spill): dragon -2.7 %, Cornell -4.2 %, random -7 %, helmet -1.5 %, spheres -0.4 % at 64-205 spp per
+// launch; launches of a few samples are slower (dragon 8 spp +7 %: more waves, fewer tiles each). 6 waves (80 VGPRs,
+// 49 spilled) lose 23 %. profiles/r02_occupancy.txt
 #ifndef TRH_MEGA_WAVES_PER_EU
-#define TRH_MEGA_WAVES_PER_EU 4
+#define TRH_MEGA_WAVES_PER_EU 5
 #endif
 template <bool STATS, bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) __attribute__((amdgpu_waves_per_eu(TRH_MEGA_WAVES_PER_EU, TRH_MEGA_WAVES_PER_EU)))
@@ -268,15 +272,39 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             // Lane state is readable from tv.node alone: >= 0 inner record, < -1 leaf, == -1 nothing to
             // traverse (finished, or no path), so each census is one v_cmp + s_bcnt1.
             const uint32_t nP = (uint32_t)__popcll(__ballot(has_path));   // constant during the traversal phase
+            // The phase ends when nobody traverses any more or when refill_thresh lanes wait for shading. Both are one
+            // test on the number of waiting lanes: nobody traversing <=> all nP lanes wait, so the limit is min(thresh, nP).
+            const uint32_t wait_limit = nP < rp.refill_thresh ? nP : rp.refill_thresh;
             // issue priority to the waves that are traversing (memory-bound steps: get their loads out first), over
             // the waves in the compute-heavy shade / generate phase: -1 % (the other way round: +2 %)
             __builtin_amdgcn_s_setprio(3);
             for (;;) {
+                // (every instruction of this census is paid once per iteration by the whole wave: 13 instructions as
+                // written here, 41 in round 1's form with its separate tests and branches -- profiles/r02_isa_breakdown.md)
+#if defined(TRH_PERTURB_SALU)   // development: what does a scalar instruction cost here? (profiles/r02_perturbation.md)
+                {
+                    uint32_t dummy = nP;
+#pragma unroll
+                    for (int q = 0; q < TRH_PERTURB_SALU; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy) : : "scc");
+                }
+#endif
+#if defined(TRH_PERTURB_VALU)   // development: ... and a vector instruction?
+                {
+                    float dummy = ps.o.x;
+#pragma unroll
+                    for (int q = 0; q < TRH_PERTURB_VALU; ++q) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
+                }
+#endif
+#if defined(TRH_PERTURB_NOP)    // development: ... and plain issue slots?
+#pragma unroll
+                for (int q = 0; q < TRH_PERTURB_NOP; ++q) asm volatile("s_nop 0");
+#endif
                 const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
                 const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
-                if ((nI | nL) == 0u || nP - nI - nL >= rp.refill_thresh) break;
+                if (nP - (nI + nL) >= wait_limit) break;
                 const unsigned long long t_step = STATS ? __builtin_readcyclecounter() : 0ull;
-                if (nI != 0u && nI * 4u >= nL * rp.sched_beta4) {
+                // nI == 0 needs no test of its own: then nL > 0 here, and 0 >= nL * beta4 is false for beta4 >= 1
+                if (nI * 4u >= nL * rp.sched_beta4) {
                     if (STATS && lane == 0) { cnt.idle_leaf += nL; cnt.idle_wait += nP - nI - nL; cnt.idle_none += 64u - nP; }
 #pragma unroll
                     for (int r = 0; r < TRH_INNER_REPEAT; ++r)
@@ -604,7 +632,7 @@ int ensure_tile_order(trh_context* c, uint32_t ntiles, uint32_t shape) {
 // 8 spp: 2.44 / 2.56; 1 spp: 16x16 pixels 1.01 ms, 16x8 0.84, 8x8 0.77.
 void choose_tiling(const trh_context* c, uint32_t spp_count, uint32_t& wl, uint32_t& hl, uint32_t& ntiles) {
     const double pixels = (double)c->sc.width * (double)c->sc.height;
-    const double resident_waves = (double)c->num_cus * 16.0;
+    const double resident_waves = (double)c->num_cus * 4.0 * TRH_MEGA_WAVES_PER_EU;
     const double p_wish = std::min(2048.0 / (double)spp_count, pixels / (resident_waves * 16.0));
     uint32_t p_log2 = 2;
     while (p_log2 < 8u && (double)(2u << p_log2) <= p_wish * 1.4142135) ++p_log2;   // nearest power of two
@@ -634,7 +662,7 @@ int launch_megakernel_tiled(trh_context* c, TileState& ts, RenderParams rp, uint
     const size_t stack_bytes = (size_t)rp.stack_entries * TRH_BLOCK * 4;
     auto acc_bytes = [&](uint32_t copies) { return (size_t)TRH_WAVES_PER_BLOCK * ((3u << (wl + hl)) + 1u) * copies * 4; };
     rp.acc_copies = 8;
-    while (rp.acc_copies > 1u && (acc_bytes(rp.acc_copies) > 4u * 3200u || (stack_bytes + acc_bytes(rp.acc_copies)) * 4u > 160u * 1024u)) rp.acc_copies >>= 1;
+    while (rp.acc_copies > 1u && (acc_bytes(rp.acc_copies) > 4u * 3200u || (stack_bytes + acc_bytes(rp.acc_copies)) * (unsigned)TRH_MEGA_WAVES_PER_EU > 160u * 1024u)) rp.acc_copies >>= 1;
     size_t lds = stack_bytes + acc_bytes(rp.acc_copies);
     lds += c->lds_pad;   // development knob: lowers occupancy to measure latency sensitivity
     int per_cu = 0;
@@ -926,7 +954,7 @@ int trh_init(int device, trh_context** ctx_out) {
     if (const char* e = getenv("TRH_BUILDER")) c->builder = strcmp(e, "lbvh") == 0 ? TRH_BUILDER_DEVICE_LBVH : TRH_BUILDER_HOST_SAH;   // default builder of this context
     if (const char* e = getenv("TRH_SCHED_BETA4")) {     // development knob
         const int v = atoi(e);
-        if (v >= 0 && v <= 256) c->sched_beta4 = (uint32_t)v;
+        if (v >= 1 && v <= 256) c->sched_beta4 = (uint32_t)v;   // >= 1: the vote relies on it (0 was round 1's while-while mode)
     }
     *ctx_out = c;
     return TRH_OK;
