@@ -90,15 +90,20 @@ struct Hit {
 
 // ------------------------------------------------------------------ camera (src/camera.h:28-35)
 DEVFN void camera_ray(const DevScene& sc, float s, float t, V3& o, V3& d) {
-    const float nx = s * 2.f - 1.f, ny = t * 2.f - 1.f, nz = 1.f;
+    // mat4 * vec4(nx, ny, 1, 1) as (m0*x + m1*y) + (m2*z + m3*w): with z = w = 1 the second half is m2 + m3 exactly,
+    // the same for every ray. The host adds it once (sc.cam_k, same fp32 add); left to the compiler it is hoisted out
+    // of the persistent loop into four VGPRs that the megakernel then spills (profiles/r02_spill_diet.md).
+    const float nx = s * 2.f - 1.f, ny = t * 2.f - 1.f;
     float p[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float a0 = sc.ivp[0 * 4 + i] * nx + sc.ivp[1 * 4 + i] * ny;
-        const float a1 = sc.ivp[2 * 4 + i] * nz + sc.ivp[3 * 4 + i] * 1.f;
-        p[i] = a0 + a1;
+        p[i] = a0 + sc.cam_k[i];
     }
     o = mk(sc.eye[0], sc.eye[1], sc.eye[2]);
+    // opaque to the optimiser from here on: a wave-uniform origin lets it hoist (eye - frame_c) of trav_begin out of
+    // the persistent loop, three more long-lived VGPRs for one v_sub each
+    asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z));
     d = normalize(mk(p[0] / p[3], p[1] / p[3], p[2] / p[3]) - o);
 }
 

@@ -43,6 +43,7 @@ struct DevScene {
     uint32_t flags;
     float eye[3];
     float ivp[16];             // column-major inverse(projection * view)
+    float cam_k[4];            // ivp column 2 * 1.f + ivp column 3 * 1.f: the ray-independent half of Camera::GetRayFrom's mat4 * vec4 (set with the camera)
     float frame_c[3];          // BVH frame: x' = (x - frame_c) * frame_s, frame_s a power of two
     float frame_sinv;          // 1 / frame_s
     float frame_inv_lim;       // largest |1/d| whose product with frame_sinv stays finite

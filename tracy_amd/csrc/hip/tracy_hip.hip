@@ -1153,6 +1153,7 @@ int scene_upload_impl(trh_context* c, const trh_scene_desc* d, const bvh::Result
     // keep the camera if one was set before (re-upload of a scene)
     memcpy(sc.eye, c->sc.eye, sizeof(sc.eye));
     memcpy(sc.ivp, c->sc.ivp, sizeof(sc.ivp));
+    memcpy(sc.cam_k, c->sc.cam_k, sizeof(sc.cam_k));
     sc.debug_view = c->debug_view;
     memcpy(sc.view3, c->view3, sizeof(sc.view3));
 
@@ -1281,6 +1282,7 @@ int trh_set_camera(trh_context* c, const float eye[3], const float inv_view_proj
     if (!c || !eye || !inv_view_proj) return fail(TRH_ERR_INVALID_ARG, "trh_set_camera: NULL argument");
     memcpy(c->sc.eye, eye, 12);
     memcpy(c->sc.ivp, inv_view_proj, 64);
+    for (int i = 0; i < 4; ++i) c->sc.cam_k[i] = inv_view_proj[2 * 4 + i] * 1.f + inv_view_proj[3 * 4 + i] * 1.f;   // dev_trace.h camera_ray
     c->has_camera = true;
     return TRH_OK;
 }
