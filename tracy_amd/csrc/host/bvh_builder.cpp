@@ -38,7 +38,7 @@ struct Ref {
     uint32_t idx;
 };
 
-float kCostTraverse = 0.5f;   // one inner-record step (two slab tests)
+float kCostTraverse = 0.8f;   // one inner-record step (two slab tests) against one triangle test; swept on the GPU, profiles/r02_bvh_knobs.md
 constexpr float kCostIntersect = 1.0f;   // one Moller-Trumbore test
 
 int levels_needed(size_t n) {  // inner-record levels a median-split subtree of n prims needs
