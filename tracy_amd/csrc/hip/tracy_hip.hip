@@ -156,10 +156,11 @@ __global__ __launch_bounds__(TRH_BLOCK) void k_megakernel_simple(DevScene sc, Re
 #ifndef TRH_INNER_REPEAT
 #define TRH_INNER_REPEAT 3
 #endif
-// Waves per SIMD the megakernel is compiled for. 5 (<= 96 VGPRs, 13 of them spilled to scratch inside shade()) against
-// 4 (119 VGPRs, no spill): dragon -2.7 %, Cornell -4.2 %, random -7 %, helmet -1.5 %, spheres -0.4 % at 64-205 spp per
-// launch; launches of a few samples are slower (dragon 8 spp +7 %: more waves, fewer tiles each). 6 waves (80 VGPRs,
-// 49 spilled) lose 23 %. profiles/r02_occupancy.txt
+// Waves per SIMD the megakernel is compiled for. 5 (<= 96 VGPRs; 6 dwords spilled, all tile-level or in the rare LDS add)
+// against 4 (119 VGPRs, no spill): dragon -10 %, Cornell -8.5 % at 64 spp per launch once the hot-path spills were gone
+// (camera constants precomputed on the host, dev_trace.h camera_ray); with them the fifth wave was worth 2.7 %. Launches
+// of a few samples are slower (dragon 8 spp +7 %: more waves, fewer tiles each). 6 waves (80 VGPRs, 23 dwords spilled in
+// shade / generate) lose 15 % even when the tree is shallow enough for six workgroups' stacks. profiles/r02_occupancy.txt
 #ifndef TRH_MEGA_WAVES_PER_EU
 #define TRH_MEGA_WAVES_PER_EU 5
 #endif
