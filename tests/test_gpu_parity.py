@@ -596,6 +596,23 @@ def test_scene_reupload_on_a_live_context(scene_loader):
     mod.Shutdown()
 
 
+def test_reupload_keeps_the_camera(scene_loader):
+    """The camera set before a (re-)upload survives it, including the host-side constants derived from it
+    (DevScene::cam_k, the ray-independent half of GetRayFrom's matrix product)."""
+    import ctypes as C
+    from tracy_amd import HipTrace
+    sc = scene_loader("spheres", 96, 54)
+    mod = HipTrace()
+    mod.Startup(sc)
+    mod.render(0, 8)
+    want, _ = mod.resolve()
+    assert mod._lib.trh_scene_upload(mod._ctx, C.byref(sc.desc)) == 0     # no trh_set_camera afterwards
+    mod.render(0, 8)
+    img, n = mod.resolve()
+    mod.Shutdown()
+    assert n == 8 and np.array_equal(img, want)
+
+
 def test_upload_from_the_bvh_cache_renders_the_same(scene_loader, tmp_path):
     from tracy_amd import HipTrace, capi
     lib = capi.hip_lib()

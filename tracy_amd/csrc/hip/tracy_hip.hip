@@ -627,14 +627,18 @@ int ensure_tile_order(trh_context* c, uint32_t ntiles, uint32_t shape) {
 }
 
 // The tiling of a launch: tile = P pixels x spp items, P = 2x2 ... 16x16 pixels. Two wishes pull on P: a tile should hold
-// enough items for the wave-local scheduler to keep its lanes busy (best about 2048 = 32 per lane, no use below 512), and
+// enough items for the wave-local scheduler to keep its lanes busy (best about 8192 = 128 per lane, no use below 512), and
 // the launch should have about 16 tiles per resident wave to balance. Measured on the dragon at 1080p (32400 tiles of 64
 // pixels = 7.9 per wave): 64 spp: 8x8 pixels 15.9 ms, 8x4 13.0, 4x4 13.6; 32 spp: 8x8 8.3, 8x4 7.1; 16 spp: 4.3 / 4.0;
 // 8 spp: 2.44 / 2.56; 1 spp: 16x16 pixels 1.01 ms, 16x8 0.84, 8x8 0.77.
+// Round 2 (5 waves per SIMD): with the balance wish in force (launches of <= 64 spp) nothing changes between 2048 and 16384
+// items; big launches like more items per tile, i.e. fewer tile drains: 512 spp per launch 77.8 ms at 2048 items (2x2
+// pixels), 76.0 at 4096, 75.6 at 8192 (4x4 pixels), 76.2 at 16384; Cornell 70.0 / 68.9 / 68.3 / 69.1. Hence 8192.
 void choose_tiling(const trh_context* c, uint32_t spp_count, uint32_t& wl, uint32_t& hl, uint32_t& ntiles) {
     const double pixels = (double)c->sc.width * (double)c->sc.height;
     const double resident_waves = (double)c->num_cus * 4.0 * TRH_MEGA_WAVES_PER_EU;
-    const double p_wish = std::min(2048.0 / (double)spp_count, pixels / (resident_waves * 16.0));
+    static const double items_wish = [] { const char* e = getenv("TRH_TILE_ITEMS"); return e && atof(e) >= 64.0 ? atof(e) : 8192.0; }();   // development knob
+    const double p_wish = std::min(items_wish / (double)spp_count, pixels / (resident_waves * 16.0));
     uint32_t p_log2 = 2;
     while (p_log2 < 8u && (double)(2u << p_log2) <= p_wish * 1.4142135) ++p_log2;   // nearest power of two
     // few samples: rather 512 items per tile than 16 tiles per wave, down to 4 tiles per wave
