@@ -638,7 +638,9 @@ void choose_tiling(const trh_context* c, uint32_t spp_count, uint32_t& wl, uint3
     const double pixels = (double)c->sc.width * (double)c->sc.height;
     const double resident_waves = (double)c->num_cus * 4.0 * TRH_MEGA_WAVES_PER_EU;
     static const double items_wish = [] { const char* e = getenv("TRH_TILE_ITEMS"); return e && atof(e) >= 64.0 ? atof(e) : 8192.0; }();   // development knob
-    const double p_wish = std::min(items_wish / (double)spp_count, pixels / (resident_waves * 16.0));
+    // more than 32 pixels per tile only for launches of few samples: rays of far-apart pixels share less (helmet 4K, 64 spp:
+    // 128-pixel tiles 20.0 ms, 32-pixel tiles 18.1)
+    const double p_wish = std::min(std::min(items_wish / (double)spp_count, pixels / (resident_waves * 16.0)), spp_count >= 64u ? 32.0 : 256.0);
     uint32_t p_log2 = 2;
     while (p_log2 < 8u && (double)(2u << p_log2) <= p_wish * 1.4142135) ++p_log2;   // nearest power of two
     // few samples: rather 512 items per tile than 16 tiles per wave, down to 4 tiles per wave
