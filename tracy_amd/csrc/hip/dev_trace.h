@@ -187,6 +187,19 @@ DEVFN void trav_begin(const DevScene& sc, Trav& tv, V3 o, V3 d, int* __restrict_
     tv.node = nan ? -1 : 0;
 }
 
+// The lane index, recomputed (two v_mbcnt) instead of kept: volatile so that the compiler neither hoists it out of a
+// persistent loop nor keeps the result alive across one.
+DEVFN uint32_t fresh_lane_id() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// A lane's stack column from any of its stack pointers: rows are TRH_BLOCK ints apart and the column is the thread's
+// index in the workgroup, so column = (pointer - base) mod TRH_BLOCK (also for the pointer one row below the sentinel).
+DEVFN int* stack_column(int* lds_base, const int* top) {
+    return lds_base + ((uint32_t)(top - lds_base) & (uint32_t)(TRH_BLOCK - 1));
+}
+
 DEVFN void trav_pop(Trav& tv) {
     tv.node = *tv.top;        // the sentinel -1 when nothing is left
     tv.top -= TRH_BLOCK;
@@ -463,8 +476,8 @@ DEVFN bool shade(const DevScene& sc, PathState& ps, const Hit& hit, Counters& cn
 DEVFN void generate(const DevScene& sc, PathState& ps, int px, int py, uint32_t sample, uint32_t seed_hash) {
     const uint32_t pixel = (uint32_t)(py * sc.width + px);
     ps.rng = path_rng_state(pixel, sample, seed_hash);
-    const float u = ((float)px + fastrand(ps.rng)) / (float)sc.width;
-    const float v = ((float)py + fastrand(ps.rng)) / (float)sc.height;
+    const float u = ((float)px + fastrand(ps.rng)) / sc.width_f;
+    const float v = ((float)py + fastrand(ps.rng)) / sc.height_f;
     camera_ray(sc, u, v, ps.o, ps.d);
     ps.throughput = mk(1.f, 1.f, 1.f);
     ps.radiance = mk(0.f, 0.f, 0.f);

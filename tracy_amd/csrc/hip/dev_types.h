@@ -39,6 +39,7 @@ struct DevScene {
     const DevMaterial* materials;
     const DevTexture* textures;
     int32_t width, height;
+    float width_f, height_f;   // (float)width, (float)height: as arguments they are scalar operands, computed in the kernel they are two more long-lived VGPRs
     uint32_t max_bounces;
     uint32_t flags;
     float eye[3];
@@ -54,6 +55,7 @@ struct DevScene {
 struct RenderParams {
     uint32_t spp_begin;
     uint32_t spp_count;
+    uint32_t spp_magic;       // floor(2^32 / spp_count) (2^32 - 1 for one sample): item / spp_count as a multiply-high + one correction
     uint32_t seed32;          // pcg_hash of the folded 64-bit seed
     uint32_t tiles_x, tiles_y;
     uint32_t tile_w_log2, tile_h_log2;   // wave tile = (1 << tile_w_log2) x (1 << tile_h_log2) pixels

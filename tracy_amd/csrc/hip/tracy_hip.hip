@@ -169,9 +169,11 @@ __global__ __launch_bounds__(TRH_BLOCK) __attribute__((amdgpu_waves_per_eu(TRH_M
 void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                                                           DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
     extern __shared__ int s_dyn[];
-    int* stack = s_dyn + threadIdx.x;
-    stack[0] = -1;   // sentinel row of this lane's stack column (dev_trace.h)
-    const int lane = threadIdx.x & 63;
+    s_dyn[threadIdx.x] = -1;   // sentinel row of this lane's stack column (dev_trace.h)
+    // Register diet (profiles/r02_register_diet.md): nothing derived from the thread index stays in a VGPR across the
+    // persistent loop. The wave's index is a scalar, the lane index is recomputed where it is needed (two v_mbcnt),
+    // and a lane finds its stack column again from its stack pointer (column = address mod one row).
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t P_log2 = rp.tile_w_log2 + rp.tile_h_log2;
     const uint32_t P = 1u << P_log2;
     // Tile accumulators: rp.acc_copies (1, 2, 4 or 8) copies per wave, a lane adds into copy `lane mod copies`. The lanes of
@@ -179,8 +181,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
     // addresses and serialise (measured: 7 % of the launch). The copy stride is odd, so the copies of a pixel lie in
     // different LDS banks.
     const uint32_t acc_stride = P * 3u + 1u;
-    float* wacc = reinterpret_cast<float*>(s_dyn + rp.stack_entries * TRH_BLOCK) + (threadIdx.x >> 6) * (acc_stride * rp.acc_copies);
-    float* const lane_acc = wacc + ((uint32_t)lane & (rp.acc_copies - 1u)) * acc_stride;
+    float* const wacc = reinterpret_cast<float*>(s_dyn + rp.stack_entries * TRH_BLOCK) + wave_in_block * (acc_stride * rp.acc_copies);   // wave-uniform
     const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
     const uint32_t total = P * rp.spp_count;   // items per tile
     Counters cnt = {};
@@ -188,6 +189,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
     if (STATS) cnt.t_start = wall_clock64();
 
     for (;;) {
+        const uint32_t lane = fresh_lane_id();
         uint32_t tile = 0;
         if (lane == 0) tile = atomicAdd(tile_counter, 1u);
         tile = __builtin_amdgcn_readfirstlane(tile);
@@ -208,7 +210,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
         tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
         tv.selx = tv.sely = tv.selz = 0x03020100u;
         tv.node = -1;
-        tv.top = stack;
+        tv.top = s_dyn + (wave_in_block * 64u + lane);
         tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
         uint32_t pix = 0;           // pixel-in-tile of the item this lane works on
         bool has_path = false;      // a traversal result is waiting to be shaded
@@ -219,17 +221,19 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             const unsigned long long t_shade = STATS ? __builtin_readcyclecounter() : 0ull;
             if (has_path && !trav_active(tv)) {
                 const bool cont = shade<STATS>(sc, ps, tv.hit, cnt);
-                if (cont) {
-                    trav_begin(sc, tv, ps.o, ps.d, stack);
-                } else {
-                    // (most paths of an emitter-lit scene under a black sky carry no light at all: x + 0 is x, skip the add)
-                    if (ps.radiance.x != 0.f || ps.radiance.y != 0.f || ps.radiance.z != 0.f) {
-                        __hip_atomic_fetch_add(&lane_acc[pix * 3 + 0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&lane_acc[pix * 3 + 1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&lane_acc[pix * 3 + 2], ps.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    has_path = false;
+                // Radiance goes to the tile accumulator as soon as it is collected (an emitter hit, or the sky at the end of
+                // the path) and is not carried through the next traversal: three registers less in the hot loop. A path adds
+                // the same terms to its pixel as before; only a path that meets light twice adds them one by one instead of
+                // their sum. (Most paths of an emitter-lit scene under a black sky carry no light at all: no add.)
+                if (ps.radiance.x != 0.f || ps.radiance.y != 0.f || ps.radiance.z != 0.f) {
+                    float* const lane_acc = wacc + ((fresh_lane_id() & (rp.acc_copies - 1u)) * acc_stride + pix * 3u);
+                    __hip_atomic_fetch_add(&lane_acc[0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&lane_acc[1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&lane_acc[2], ps.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                ps.radiance = mk(0.f, 0.f, 0.f);
+                if (cont) trav_begin(sc, tv, ps.o, ps.d, stack_column(s_dyn, tv.top));
+                else has_path = false;
             }
             const unsigned long long t_refill = STATS ? __builtin_readcyclecounter() : 0ull;
             if (STATS) cnt.cyc[2] += t_refill - t_shade;
@@ -243,14 +247,18 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                     if (item < total) {
                         // items run sample-major: the 64 lanes of a wave hold samples of one or two pixels, so their camera
                         // rays walk the same nodes (-5 % dragon, -6 % spheres against pixel-major order)
-                        pix = item / rp.spp_count;
-                        const uint32_t sample = rp.spp_begin + (item - pix * rp.spp_count);
+                        // item / spp_count without the compiler's per-launch reciprocal (a VGPR for the whole kernel):
+                        // floor(item * floor(2^32 / spp) / 2^32) is the quotient or one less (item < 2^24, spp <= 2^16)
+                        pix = __umulhi(item, rp.spp_magic);
+                        uint32_t sample = item - pix * rp.spp_count;
+                        if (sample >= rp.spp_count) { pix += 1u; sample -= rp.spp_count; }
+                        sample += rp.spp_begin;
                         const int px = tile_x0 + (int)(pix & ((1u << rp.tile_w_log2) - 1u));
                         const int py = tile_y0 + (int)(pix >> rp.tile_w_log2);
                         if (px < sc.width && py < sc.height) {
                             if (STATS) { cnt.l_gen += 1; if (first_active_lane()) cnt.w_gen += 1; }
                             generate(sc, ps, px, py, sample, rp.seed32);
-                            trav_begin(sc, tv, ps.o, ps.d, stack);
+                            trav_begin(sc, tv, ps.o, ps.d, stack_column(s_dyn, tv.top));
                             has_path = true;
                         }   // else: pixel outside the frame (partial edge tile): the item is dropped
                     } else {
@@ -306,13 +314,13 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
                 const unsigned long long t_step = STATS ? __builtin_readcyclecounter() : 0ull;
                 // nI == 0 needs no test of its own: then nL > 0 here, and 0 >= nL * beta4 is false for beta4 >= 1
                 if (nI * 4u >= nL * rp.sched_beta4) {
-                    if (STATS && lane == 0) { cnt.idle_leaf += nL; cnt.idle_wait += nP - nI - nL; cnt.idle_none += 64u - nP; }
+                    if (STATS && fresh_lane_id() == 0u) { cnt.idle_leaf += nL; cnt.idle_wait += nP - nI - nL; cnt.idle_none += 64u - nP; }
 #pragma unroll
                     for (int r = 0; r < TRH_INNER_REPEAT; ++r)
-                        if (tv.node >= 0) trav_inner<STATS, N16>(sc, ps.o, tv, stack, cnt);
+                        if (tv.node >= 0) trav_inner<STATS, N16>(sc, ps.o, tv, nullptr, cnt);
                     if (STATS) cnt.cyc[0] += __builtin_readcyclecounter() - t_step;
                 } else {
-                    if (tv.node < -1) trav_leaf<STATS>(sc, ps.o, ps.d, tv, stack, cnt);
+                    if (tv.node < -1) trav_leaf<STATS>(sc, ps.o, ps.d, tv, nullptr, cnt);
                     if (STATS) cnt.cyc[1] += __builtin_readcyclecounter() - t_step;
                 }
             }
@@ -320,7 +328,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
         }
         // ---- flush the tile: plain read-modify-write, the tile belongs to this wave
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < P; i += 64) {
+        for (uint32_t i = fresh_lane_id(); i < P; i += 64) {
             const int px = tile_x0 + (int)(i & ((1u << rp.tile_w_log2) - 1u));
             const int py = tile_y0 + (int)(i >> rp.tile_w_log2);
             if (px < sc.width && py < sc.height) {
@@ -337,7 +345,7 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (rp.tile_cost && lane == 0) {
+        if (rp.tile_cost && fresh_lane_id() == 0u) {
             const unsigned long long dt = __builtin_readcyclecounter() - t_tile;
             rp.tile_cost[tile] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
         }
@@ -661,6 +669,7 @@ int launch_megakernel_tiled(trh_context* c, TileState& ts, RenderParams rp, uint
     rp.stack_entries = std::max<uint32_t>(c->bvh.max_depth, 1u) + 1u;   // + the sentinel row
     rp.refill_thresh = c->refill_thresh;
     rp.sched_beta4 = c->sched_beta4;
+    rp.spp_magic = rp.spp_count <= 1u ? 0xffffffffu : (uint32_t)((1ull << 32) / rp.spp_count);
     if (ordered) {
         rp.tile_order = ts.order_valid ? ts.order : nullptr;
         rp.tile_cost = ts.cost;
@@ -1155,6 +1164,8 @@ int scene_upload_impl(trh_context* c, const trh_scene_desc* d, const bvh::Result
     sc.textures = dt;
     sc.width = (int32_t)d->width;
     sc.height = (int32_t)d->height;
+    sc.width_f = (float)sc.width;
+    sc.height_f = (float)sc.height;
     sc.max_bounces = d->max_bounces ? d->max_bounces : 1;
     sc.flags = d->flags;
     // keep the camera if one was set before (re-upload of a scene)
