@@ -61,22 +61,22 @@ PHASES = {
         ("traversal phase exit, tile-done test", "141", "144"),
         ("tile flush (LDS copies -> accum), tile cost, epilogue counters", "144", None),
     ],
-    "r02_final_megakernel_isa.s": [     # round-2 final kernel (trimmed vote, bitwise near/far swap, 96 VGPRs)
+    "r02_final_megakernel_isa.s": [     # round-2 final kernel (trimmed vote, bitwise near/far swap, register diet, 96 VGPRs)
         ("kernel prologue, tile fetch and accumulator clear", 0, "17"),
-        ("shade: attribute interpolation, textures, Scatter, sky, roulette, LDS accumulate", "18", "83"),
-        ("refill: ballot/mbcnt item hand-out + generate (RNG, camera ray, trav_begin)", "83", "91"),
-        ("traversal phase entry (nP census, wait limit, setprio)", "91", "93"),
-        ("loop back-edge blocks (exec restores, exit branch)", "93", "96"),
-        ("vote: census of inner / leaf lanes, exit test, majority rule (per iteration)", "96", ("96", 22)),
-        ("inner-step dispatch (exec masks for the three unrolled steps)", ("96", 22), "101"),
-        ("inner step 3 of 3 (record fetch, 6 v_perm, 12 v_fma_mix, slab min/max, near/far, push/pop)", "101", "102"),
-        ("step join", "102", ("103", 3)),
-        ("triangle step: record fetch, Moller-Trumbore, 1/det, candidate test, leaf advance / pop", ("103", 3), "121"),
-        ("inner step 1 of 3", "121", "122"),
-        ("inner step 2 of 3", "122", "123"),
-        ("accept_candidate: cross-mesh tie rule (rare branch of the triangle step, IEEE 1/d)", "123", "130"),
-        ("traversal phase exit, tile-done test", "130", "133"),
-        ("tile flush (LDS copies -> accum), tile cost, epilogue counters", "133", None),
+        ("shade: attribute interpolation, textures, Scatter, sky, roulette, LDS accumulate", "18", "81"),
+        ("refill: ballot/mbcnt item hand-out + generate (RNG, camera ray, trav_begin)", "81", "89"),
+        ("traversal phase entry (nP census, wait limit, setprio)", "89", "91"),
+        ("loop back-edge blocks (exec restores, exit branch)", "91", "94"),
+        ("vote: census of inner / leaf lanes, exit test, majority rule (per iteration)", "94", ("94", 22)),
+        ("inner-step dispatch (exec masks for the three unrolled steps)", ("94", 22), "99"),
+        ("inner step 3 of 3 (record fetch, 6 v_perm, 12 v_fma_mix, slab min/max, near/far, push/pop)", "99", "100"),
+        ("step join", "100", ("101", 3)),
+        ("triangle step: record fetch, Moller-Trumbore, 1/det, candidate test, leaf advance / pop", ("101", 3), "119"),
+        ("inner step 1 of 3", "119", "120"),
+        ("inner step 2 of 3", "120", "121"),
+        ("accept_candidate: cross-mesh tie rule (rare branch of the triangle step, IEEE 1/d)", "121", "128"),
+        ("traversal phase exit, tile-done test", "128", "131"),
+        ("tile flush (LDS copies -> accum), tile cost, epilogue counters", "131", None),
     ],
 }
 
