@@ -275,6 +275,12 @@ int reduce_to_root(trh_group* g) {
             (void)g_rccl.GroupEnd();
             return fail(TRH_ERR_STATE, "trh_group: devices hold frames of different sizes");
         }
+        // (the examples of the library make the communicator's device current before every call of a single-threaded group;
+        // later versions no longer need it, and it costs nothing)
+        if (hipSetDevice(trh_internal::device_of(g->ctx[(size_t)i])) != hipSuccess) {
+            (void)g_rccl.GroupEnd();
+            return fail(TRH_ERR_HIP, "trh_group: hipSetDevice failed before ncclReduce");
+        }
         const ncclResult_t r = g_rccl.Reduce(acc, i == 0 ? g->reduced : acc, floats, ncclFloat32, ncclSum, 0, g->comms[(size_t)i], trh_internal::stream_of(g->ctx[(size_t)i]));
         if (r != ncclSuccess) {
             (void)g_rccl.GroupEnd();
@@ -282,6 +288,7 @@ int reduce_to_root(trh_group* g) {
         }
     }
     NCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipSetDevice(trh_internal::device_of(g->ctx[0])));
     return TRH_OK;
 }
 
