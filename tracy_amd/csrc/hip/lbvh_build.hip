@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "../host/half_round.h"
@@ -31,6 +32,7 @@ namespace lbvh {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kDepthAim = 27;             // see build(): the depth the guard aims for
 constexpr uint32_t kLeafMax = 4;          // triangles per collapsed leaf (the link format allows bvh::kMaxLeafSize = 8)
 constexpr float kCostTraverse = 0.5f;     // same constants as the host builder: sah_cost is comparable
 constexpr float kCostIntersect = 1.0f;
@@ -142,7 +144,7 @@ __host__ __device__ inline int levels_needed(uint32_t n) {   // record levels a 
 }
 
 // child links: >= 0 inner node (index = its split position), < -1 leaf ~((first << 4) | count)
-__global__ __launch_bounds__(kBlock) void k_level(const Item* __restrict__ items, int n_items, int depth, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(kBlock) void k_level(const Item* __restrict__ items, int n_items, int depth, int depth_limit, const uint64_t* __restrict__ keys,
                                                   const Tri* __restrict__ tris, const uint32_t* __restrict__ prim, Item* __restrict__ next_items,
                                                   const unsigned int* __restrict__ item_count, unsigned int* __restrict__ next_count, Stats* __restrict__ stats, int* __restrict__ parent, int* child,
                                                   uint32_t* __restrict__ live, Box* leaf_box, Box* node_box, unsigned int* arrived, int* __restrict__ root_out) {
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_level(const Item* __restrict__ items
             }
             const uint32_t nl = (uint32_t)(lo - it.lo + 1), nr = count - nl;
             const int need = levels_needed(nl) > levels_needed(nr) ? levels_needed(nl) : levels_needed(nr);
-            if (depth + need <= bvh::kMaxDepth) gamma = lo;
+            if (depth + need <= depth_limit) gamma = lo;
         }
         parent[gamma] = it.parent;
         live[gamma] = 1u;
@@ -433,9 +435,16 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     LB_TRY(hipMemsetAsync(d_counts, 0, ((size_t)bvh::kMaxDepth + 3) * sizeof(unsigned int), stream));
     const unsigned int one = 1;
     LB_TRY(hipMemcpyAsync(d_counts + 1, &one, sizeof(one), hipMemcpyHostToDevice, stream));
+    // The depth of the tree is the number of LDS stack rows the render kernels need: above 30 rows a CU holds four
+    // workgroups instead of five. The guard therefore aims for kDepthAim levels as long as that leaves a median tree of
+    // this many triangles ten levels of slack (dragon 100 k: depth 31 -> 27, render 14.8 -> 13.2 ms; with less slack the
+    // forced median splits cost more than the fifth workgroup brings: 1.6 M triangles at 27 levels 22.4 ms against 20.5
+    // at 29-32). Development override: TRH_LBVH_DEPTH.
+    int depth_limit = std::min(bvh::kMaxDepth, std::max(kDepthAim, levels_needed((uint32_t)n) + 10));
+    if (const char* e = getenv("TRH_LBVH_DEPTH")) depth_limit = std::max(levels_needed((uint32_t)n) + 1, std::min(bvh::kMaxDepth, atoi(e)));
     for (int depth = 1; depth <= bvh::kMaxDepth + 1; ++depth) {
         const size_t bound = depth > 27 ? n : std::min<size_t>(n, (size_t)1 << (depth - 1));
-        hipLaunchKernelGGL(k_level, dim3((unsigned)((bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_items_a, (int)bound, depth, d_keys_sorted, d_tris, d_prim,
+        hipLaunchKernelGGL(k_level, dim3((unsigned)((bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_items_a, (int)bound, depth, depth_limit, d_keys_sorted, d_tris, d_prim,
                            d_items_b, d_counts + depth, d_counts + depth + 1, d_stats, d_parent, d_child, d_live, d_leaf_box, d_node_box, d_arrived, d_root);
         LB_TRY(hipGetLastError());
         std::swap(d_items_a, d_items_b);
