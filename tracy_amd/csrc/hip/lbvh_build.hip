@@ -4,6 +4,8 @@
 //   k_bounds      scene box + centroid box: wave reduction, then ordered-integer atomic min / max
 //   k_morton      63-bit Morton code of every centroid (21 bits per axis inside the centroid box)
 //   radix sort    hipcub::DeviceRadixSort::SortPairs (code, triangle) -- stable, so equal codes keep input order
+//   clusters      (>= 4096 triangles) ranges that share their top 6..15 code bits; their boxes go to the host, which builds
+//                 the UPPER levels with binned SAH over the cluster boxes (TopBuilder) and seeds one range per cluster
 //   k_level       top-down over the sorted codes, one launch per tree level (<= 32): a range of > 4 triangles is
 //                 split where the highest differing code bit flips (the LBVH split), or at its median when
 //                 the codes are equal or the remaining depth budget demands it (the depth guard of the host
@@ -32,6 +34,7 @@ namespace lbvh {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kLinkUnknown = (int)0x80000000;   // k_scatter_top: a child link the linear build fills in
 constexpr int kDepthAim = 27;             // see build(): the depth the guard aims for
 constexpr uint32_t kLeafMax = 4;          // triangles per collapsed leaf (the link format allows bvh::kMaxLeafSize = 8)
 constexpr float kCostTraverse = 0.5f;     // same constants as the host builder: sah_cost is comparable
@@ -135,7 +138,43 @@ __global__ __launch_bounds__(kBlock) void k_morton(const Tri* __restrict__ tris,
     vals[i] = i;
 }
 
-struct Item { int lo, hi, parent, side; };   // a range of sorted positions, the node above it and which child it is
+// ---- Morton clusters (the SAH top tree of build()): a cluster = the sorted positions that share the top `shift`ed bits
+__global__ __launch_bounds__(kBlock) void k_cluster_flags(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0u || (keys[i] >> shift) != (keys[i - 1u] >> shift)) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_cluster_starts(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ index, uint32_t n, uint32_t* __restrict__ starts) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) starts[index[i]] = i;
+}
+__global__ __launch_bounds__(kBlock) void k_cluster_boxes(const Tri* __restrict__ tris, const uint32_t* __restrict__ prim, const uint32_t* __restrict__ starts, uint32_t n_clusters,
+                                                          uint32_t n, Box* __restrict__ boxes) {
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= n_clusters) return;
+    const uint32_t lo = starts[c], hi = c + 1u < n_clusters ? starts[c + 1u] : n;
+    Box b = tri_box(tris[prim[lo]]);
+    for (uint32_t p = lo + 1u; p < hi; ++p) {
+        const Box t = tri_box(tris[prim[p]]);
+        for (int a = 0; a < 3; ++a) { b.mn[a] = fminf(b.mn[a], t.mn[a]); b.mx[a] = fmaxf(b.mx[a], t.mx[a]); }
+    }
+    boxes[c] = b;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter_top(const int* __restrict__ ids, const int* __restrict__ parents, const int* __restrict__ children, int n_top,
+                                                        int* __restrict__ parent, int* __restrict__ child, uint32_t* __restrict__ live) {
+    const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (t >= n_top) return;
+    const int id = ids[t];
+    parent[id] = parents[t];
+    live[id] = 1u;
+    // links to cluster ranges are written by the linear build (k_level); only links between top nodes are known here
+    if (children[2 * t] != kLinkUnknown) child[2 * id] = children[2 * t];
+    if (children[2 * t + 1] != kLinkUnknown) child[2 * id + 1] = children[2 * t + 1];
+}
+
+struct Item { int lo, hi, parent, side, depth; };   // a range of sorted positions, the node above it, which child it is, the depth of the record it would become
 
 __host__ __device__ inline int levels_needed(uint32_t n) {   // record levels a median-split sub-tree of n triangles needs
     int l = 0;
@@ -144,13 +183,14 @@ __host__ __device__ inline int levels_needed(uint32_t n) {   // record levels a 
 }
 
 // child links: >= 0 inner node (index = its split position), < -1 leaf ~((first << 4) | count)
-__global__ __launch_bounds__(kBlock) void k_level(const Item* __restrict__ items, int n_items, int depth, int depth_limit, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(kBlock) void k_level(const Item* __restrict__ items, int n_items, int depth_limit, const uint64_t* __restrict__ keys,
                                                   const Tri* __restrict__ tris, const uint32_t* __restrict__ prim, Item* __restrict__ next_items,
                                                   const unsigned int* __restrict__ item_count, unsigned int* __restrict__ next_count, Stats* __restrict__ stats, int* __restrict__ parent, int* child,
                                                   uint32_t* __restrict__ live, Box* leaf_box, Box* node_box, unsigned int* arrived, int* __restrict__ root_out) {
     const int k = (int)(blockIdx.x * kBlock + threadIdx.x);
     if (k >= n_items || (unsigned int)k >= *item_count) return;   // n_items: the launch's upper bound; *item_count: what the level above queued
     const Item it = items[k];
+    const int depth = it.depth;
     const uint32_t count = (uint32_t)(it.hi - it.lo + 1);
     if (count > kLeafMax) {
         // ---- inner node: LBVH split = last position whose code shares more than the range's common prefix with the first
@@ -170,11 +210,12 @@ __global__ __launch_bounds__(kBlock) void k_level(const Item* __restrict__ items
         }
         parent[gamma] = it.parent;
         live[gamma] = 1u;
-        if ((uint32_t)(__ffsll((long long)__ballot(1)) - 1) == (threadIdx.x & 63u)) atomicMax(&stats->max_depth, (uint32_t)depth);   // one lane per wave
+        // (ranges of one generation sit at different depths once the build is seeded: every thread checks, few need the atomic)
+        if ((uint32_t)depth > __hip_atomic_load(&stats->max_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats->max_depth, (uint32_t)depth);
         if (it.parent >= 0) child[2 * it.parent + it.side] = gamma; else *root_out = gamma;
         const unsigned int pos = atomicAdd(next_count, 2u);
-        next_items[pos] = Item{it.lo, gamma, gamma, 0};
-        next_items[pos + 1] = Item{gamma + 1, it.hi, gamma, 1};
+        next_items[pos] = Item{it.lo, gamma, gamma, 0, depth + 1};
+        next_items[pos + 1] = Item{gamma + 1, it.hi, gamma, 1, depth + 1};
         return;
     }
     // ---- leaf: box of its triangles, then up the tree
@@ -305,6 +346,93 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const Tri* __restrict__ tr
     r[11] = 0.f;
 }
 
+// ---- SAH top tree over the Morton clusters (host, one thread: <= 32768 clusters). The Morton curve clusters the upper
+// levels of a scene badly (a split at the highest differing bit is a spatial-median split, whatever the geometry), and that
+// is where a linear BVH loses against SAH; inside a small cluster the difference is nil. So the upper levels are
+// built with binned SAH (16 bins, cost = half area x triangle count) over the cluster boxes, and every cluster becomes a
+// seed range for the linear build below its leaf.
+struct TopNode { int parent, side, child[2], depth; };   // child: >= 0 top node, < 0: ~cluster
+struct Cluster { Box box; float c[3]; uint32_t lo, hi, count; };
+
+struct TopBuilder {
+    const std::vector<Cluster>& cl;
+    std::vector<int> order;
+    std::vector<TopNode> nodes;
+    int max_seed_depth;   // deepest record a cluster's root may be
+
+    static int ceil_log2(uint32_t k) { int l = 0; while ((1u << l) < k) ++l; return l; }
+
+    // builds the sub-tree over order[begin, end) whose root record sits at `depth`; returns its link
+    int build(int begin, int end, int depth, int parent, int side) {
+        const int k = end - begin;
+        if (k == 1) return ~order[(size_t)begin];
+        const int me = (int)nodes.size();
+        nodes.push_back(TopNode{parent, side, {0, 0}, depth});
+        // bounds of the centroids, bins
+        float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = begin; i < end; ++i)
+            for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], cl[(size_t)order[(size_t)i]].c[a]); cmx[a] = std::max(cmx[a], cl[(size_t)order[(size_t)i]].c[a]); }
+        constexpr int B = 16;
+        float best = FLT_MAX;
+        int best_axis = -1, best_bin = -1;
+        for (int a = 0; a < 3; ++a) {
+            const float ext = cmx[a] - cmn[a];
+            if (!(ext > 0.f)) continue;
+            Box bb[B];
+            uint32_t cnt[B] = {0}, num[B] = {0};
+            for (int b = 0; b < B; ++b) for (int x = 0; x < 3; ++x) { bb[b].mn[x] = FLT_MAX; bb[b].mx[x] = -FLT_MAX; }
+            const float scale = (float)B / ext;
+            for (int i = begin; i < end; ++i) {
+                const Cluster& c = cl[(size_t)order[(size_t)i]];
+                const int b = std::min(B - 1, std::max(0, (int)((c.c[a] - cmn[a]) * scale)));
+                for (int x = 0; x < 3; ++x) { bb[b].mn[x] = std::min(bb[b].mn[x], c.box.mn[x]); bb[b].mx[x] = std::max(bb[b].mx[x], c.box.mx[x]); }
+                cnt[b] += c.count;
+                num[b] += 1u;
+            }
+            float rarea[B];
+            uint32_t rcnt[B], rnum[B];
+            Box acc;
+            for (int x = 0; x < 3; ++x) { acc.mn[x] = FLT_MAX; acc.mx[x] = -FLT_MAX; }
+            uint32_t c = 0, m = 0;
+            auto area = [](const Box& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return (dx < 0.f || dy < 0.f || dz < 0.f) ? 0.f : dx * dy + dy * dz + dz * dx; };
+            for (int b = B - 1; b > 0; --b) {
+                for (int x = 0; x < 3; ++x) { acc.mn[x] = std::min(acc.mn[x], bb[b].mn[x]); acc.mx[x] = std::max(acc.mx[x], bb[b].mx[x]); }
+                c += cnt[b]; m += num[b];
+                rarea[b] = area(acc); rcnt[b] = c; rnum[b] = m;
+            }
+            Box lacc;
+            for (int x = 0; x < 3; ++x) { lacc.mn[x] = FLT_MAX; lacc.mx[x] = -FLT_MAX; }
+            uint32_t lc = 0, lm = 0;
+            for (int b = 0; b < B - 1; ++b) {
+                for (int x = 0; x < 3; ++x) { lacc.mn[x] = std::min(lacc.mn[x], bb[b].mn[x]); lacc.mx[x] = std::max(lacc.mx[x], bb[b].mx[x]); }
+                lc += cnt[b]; lm += num[b];
+                if (lm == 0 || rnum[b + 1] == 0) continue;
+                // depth guard: both sides must still fit below max_seed_depth
+                if (depth + 1 + ceil_log2(std::max(lm, rnum[b + 1])) > max_seed_depth) continue;
+                const float cost = area(lacc) * (float)lc + rarea[b + 1] * (float)rcnt[b + 1];
+                if (cost < best) { best = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        int mid = begin + k / 2;
+        if (best_axis >= 0) {
+            const float scale = (float)B / (cmx[best_axis] - cmn[best_axis]);
+            auto it = std::stable_partition(order.begin() + begin, order.begin() + end, [&](int ci) {
+                return std::min(B - 1, std::max(0, (int)((cl[(size_t)ci].c[best_axis] - cmn[best_axis]) * scale))) <= best_bin;
+            });
+            mid = (int)(it - order.begin());
+        } else {   // median by number of clusters along the widest axis (equal centroids, or the depth guard)
+            int axis = 0;
+            for (int a = 1; a < 3; ++a) if (cmx[a] - cmn[a] > cmx[axis] - cmn[axis]) axis = a;
+            std::stable_sort(order.begin() + begin, order.begin() + end, [&](int x, int y) { return cl[(size_t)x].c[axis] < cl[(size_t)y].c[axis]; });
+        }
+        const int c0 = build(begin, mid, depth + 1, me, 0);
+        const int c1 = build(mid, end, depth + 1, me, 1);
+        nodes[(size_t)me].child[0] = c0;
+        nodes[(size_t)me].child[1] = c1;
+        return me;
+    }
+};
+
 // One arena for every temporary (a hipMalloc costs more than most of these kernels), freed on every return path;
 // the arrays that outlive the build are separate allocations.
 struct Scratch {
@@ -353,8 +481,10 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     size_t sort_bytes = 0, scan_bytes = 0;
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ni, 0, 63, stream));
     LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, n_inner, stream));
+    size_t scan_bytes_n = 0;
+    LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes_n, (uint32_t*)nullptr, (uint32_t*)nullptr, ni, stream));
     // triangles 40, keys 2 x 8, values 4, parent 4, child links 8, boxes 2 x 24, counters 3 x 4, work queues 2 x 16 bytes per triangle
-    LB_TRY(tmp.reserve(n * 200 + sort_bytes + scan_bytes + (64u << 10)));
+    LB_TRY(tmp.reserve(n * 224 + sort_bytes + scan_bytes + scan_bytes_n + (2u << 20)));
     Tri* d_tris = nullptr;
     LB_TRY(tmp.alloc(&d_tris, n));
     LB_TRY(hipMemcpyAsync(d_tris, tris.data(), n * sizeof(Tri), hipMemcpyHostToDevice, stream));
@@ -422,8 +552,123 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     LB_TRY(tmp.alloc(&d_items_b, n));
     LB_TRY(hipMemsetAsync(d_arrived, 0, (size_t)n_inner * sizeof(unsigned int), stream));
     LB_TRY(hipMemsetAsync(d_live, 0, (size_t)n_inner * sizeof(uint32_t), stream));
-    const Item root_item{0, ni - 1, -1, 0};
-    LB_TRY(hipMemcpyAsync(d_items_a, &root_item, sizeof(Item), hipMemcpyHostToDevice, stream));
+    // (the depth limit, moved up from the level loop: the seeding needs it)
+    // The depth of the tree is the number of LDS stack rows the render kernels need: above 30 rows a CU holds four
+    // workgroups instead of five. The guard therefore aims for kDepthAim levels as long as that leaves a median tree of
+    // this many triangles ten levels of slack (dragon 100 k: depth 31 -> 27, render 14.8 -> 13.2 ms; with less slack the
+    // forced median splits cost more than the fifth workgroup brings: 1.6 M triangles at 27 levels 22.4 ms against 20.5
+    // at 29-32). Development override: TRH_LBVH_DEPTH.
+    int depth_limit = std::min(bvh::kMaxDepth, std::max(kDepthAim, levels_needed((uint32_t)n) + 10));
+    if (const char* e = getenv("TRH_LBVH_DEPTH")) depth_limit = std::max(levels_needed((uint32_t)n) + 1, std::min(bvh::kMaxDepth, atoi(e)));
+
+    // ---- seeds: the whole range under no parent (plain linear BVH), or one range per Morton cluster under an SAH top tree
+    size_t n_seeds = 1;
+    uint32_t top_depth = 0;
+    bool seeded = false;
+    const char* top_env = getenv("TRH_LBVH_TOP");   // development override: 0 = plain linear BVH
+    if (!(top_env && atoi(top_env) == 0) && n >= 4096) {
+        // cluster = shared top `bits` Morton bits (a cube of the centroid grid), about 8 triangles each where 2^15 cubes
+        // allow it (dragon 100 k: 32 per cluster 12.4 ms per 64 spp, 8 per cluster 11.9; more cubes cost host time)
+        int bits = 6;
+        size_t per_cluster = 8;
+        if (const char* e = getenv("TRH_LBVH_CLUSTER")) per_cluster = (size_t)std::max(1, atoi(e));   // development knob
+        while (bits < 15 && ((size_t)1 << bits) * per_cluster < n) bits += 3;
+        uint32_t *d_flags = nullptr, *d_cidx = nullptr, *d_starts = nullptr;
+        unsigned char* d_scan2 = nullptr;
+        Box* d_cboxes = nullptr;
+        LB_TRY(tmp.alloc(&d_flags, n));
+        LB_TRY(tmp.alloc(&d_cidx, n));
+        LB_TRY(tmp.alloc(&d_scan2, scan_bytes_n));
+        hipLaunchKernelGGL(k_cluster_flags, dim3(grid_n), dim3(kBlock), 0, stream, d_keys_sorted, (uint32_t)n, 63 - bits, d_flags);
+        LB_TRY(hipGetLastError());
+        LB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan2, scan_bytes_n, d_flags, d_cidx, ni, stream));
+        uint32_t last_flag = 0, last_cidx = 0;
+        LB_TRY(hipMemcpyAsync(&last_flag, d_flags + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        LB_TRY(hipMemcpyAsync(&last_cidx, d_cidx + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        LB_TRY(hipStreamSynchronize(stream));
+        const uint32_t n_clusters = last_cidx + last_flag;
+        if (n_clusters >= 2 && n_clusters <= (1u << 15)) {
+            LB_TRY(tmp.alloc(&d_starts, n_clusters));
+            LB_TRY(tmp.alloc(&d_cboxes, n_clusters));
+            hipLaunchKernelGGL(k_cluster_starts, dim3(grid_n), dim3(kBlock), 0, stream, d_flags, d_cidx, (uint32_t)n, d_starts);
+            LB_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_cluster_boxes, dim3((n_clusters + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_tris, d_prim, d_starts, n_clusters, (uint32_t)n, d_cboxes);
+            LB_TRY(hipGetLastError());
+            std::vector<uint32_t> starts(n_clusters);
+            std::vector<Box> cboxes(n_clusters);
+            LB_TRY(hipMemcpyAsync(starts.data(), d_starts, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, stream));
+            LB_TRY(hipMemcpyAsync(cboxes.data(), d_cboxes, (size_t)n_clusters * sizeof(Box), hipMemcpyDeviceToHost, stream));
+            LB_TRY(hipStreamSynchronize(stream));
+            std::vector<Cluster> cl(n_clusters);
+            uint32_t biggest = 0;
+            for (uint32_t c = 0; c < n_clusters; ++c) {
+                cl[c].box = cboxes[c];
+                cl[c].lo = starts[c];
+                cl[c].hi = (c + 1 < n_clusters ? starts[c + 1] : (uint32_t)n) - 1u;
+                cl[c].count = cl[c].hi - cl[c].lo + 1u;
+                for (int a = 0; a < 3; ++a) cl[c].c[a] = 0.5f * (cboxes[c].mn[a] + cboxes[c].mx[a]);
+                biggest = std::max(biggest, cl[c].count);
+            }
+            // a cluster's root record at depth D needs D + levels_needed(count) <= depth_limit to be finishable by medians
+            const int max_seed_depth = depth_limit - levels_needed(biggest);
+            if (1 + TopBuilder::ceil_log2(n_clusters) <= max_seed_depth) {
+                TopBuilder tb{cl, {}, {}, max_seed_depth};
+                tb.order.resize(n_clusters);
+                for (uint32_t c = 0; c < n_clusters; ++c) tb.order[c] = (int)c;
+                tb.nodes.reserve(n_clusters);
+                const int root_link = tb.build(0, (int)n_clusters, 1, -1, 0);
+                // a top node takes the last sorted position of a cluster as its index: the linear build below uses the
+                // positions [lo, hi - 1] of a range for its own nodes, so these are free (n_clusters - 1 nodes, and the
+                // last cluster's last position, n - 1, is outside the node arrays and stays unused)
+                auto node_id = [&](int t) { return (int)cl[(size_t)t].hi; };
+                std::vector<Item> seeds(n_clusters);
+                std::vector<int> h_parent(tb.nodes.size()), h_ids(tb.nodes.size());
+                std::vector<int> h_child(tb.nodes.size() * 2);
+                size_t ns = 0;
+                for (size_t t = 0; t < tb.nodes.size(); ++t) {
+                    const TopNode& tn = tb.nodes[t];
+                    h_ids[t] = node_id((int)t);
+                    h_parent[t] = tn.parent >= 0 ? node_id(tn.parent) : -1;
+                    top_depth = std::max(top_depth, (uint32_t)tn.depth);
+                    for (int sd = 0; sd < 2; ++sd) {
+                        const int link = tn.child[sd];
+                        if (link >= 0) h_child[2 * t + sd] = node_id(link);
+                        else {
+                            const Cluster& c = cl[(size_t)~link];
+                            h_child[2 * t + sd] = kLinkUnknown;   // written by the range's own thread (inner node or leaf)
+                            seeds[ns++] = Item{(int)c.lo, (int)c.hi, node_id((int)t), sd, tn.depth + 1};
+                        }
+                    }
+                }
+                if (root_link >= 0 && ns == n_clusters) {
+                    // scatter the top nodes into the node arrays (a few thousand words: one small kernel-free path via
+                    // per-array staging would need index lists; the arrays are written entry by entry from pinned-less
+                    // host memory in three strided copies instead)
+                    int *d_ids = nullptr, *d_hp = nullptr, *d_hc = nullptr;
+                    LB_TRY(tmp.alloc(&d_ids, tb.nodes.size()));
+                    LB_TRY(tmp.alloc(&d_hp, tb.nodes.size()));
+                    LB_TRY(tmp.alloc(&d_hc, tb.nodes.size() * 2));
+                    LB_TRY(hipMemcpyAsync(d_ids, h_ids.data(), h_ids.size() * 4, hipMemcpyHostToDevice, stream));
+                    LB_TRY(hipMemcpyAsync(d_hp, h_parent.data(), h_parent.size() * 4, hipMemcpyHostToDevice, stream));
+                    LB_TRY(hipMemcpyAsync(d_hc, h_child.data(), h_child.size() * 4, hipMemcpyHostToDevice, stream));
+                    hipLaunchKernelGGL(k_scatter_top, dim3((unsigned)((tb.nodes.size() + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_ids, d_hp, d_hc, (int)tb.nodes.size(),
+                                       d_parent, d_child, d_live);
+                    LB_TRY(hipGetLastError());
+                    const int root_id = node_id(root_link);
+                    LB_TRY(hipMemcpyAsync(d_root, &root_id, 4, hipMemcpyHostToDevice, stream));
+                    LB_TRY(hipMemcpyAsync(d_items_a, seeds.data(), ns * sizeof(Item), hipMemcpyHostToDevice, stream));
+                    LB_TRY(hipStreamSynchronize(stream));   // the host vectors above go out of scope
+                    n_seeds = ns;
+                    seeded = true;
+                }
+            }
+        }
+    }
+    if (!seeded) {
+        const Item root_item{0, ni - 1, -1, 0, 1};
+        LB_TRY(hipMemcpyAsync(d_items_a, &root_item, sizeof(Item), hipMemcpyHostToDevice, stream));
+        top_depth = 0;
+    }
     // Every level is launched with an upper bound of its queue length (2^(depth-1), at most n ranges) and reads the
     // real length from the device: no host round trip per level. The depth guard ends the tree at kMaxDepth records;
     // level kMaxDepth + 1 only holds leaves.
@@ -433,18 +678,13 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     unsigned int* d_counts = nullptr;
     LB_TRY(tmp.alloc(&d_counts, (size_t)bvh::kMaxDepth + 3));
     LB_TRY(hipMemsetAsync(d_counts, 0, ((size_t)bvh::kMaxDepth + 3) * sizeof(unsigned int), stream));
-    const unsigned int one = 1;
-    LB_TRY(hipMemcpyAsync(d_counts + 1, &one, sizeof(one), hipMemcpyHostToDevice, stream));
-    // The depth of the tree is the number of LDS stack rows the render kernels need: above 30 rows a CU holds four
-    // workgroups instead of five. The guard therefore aims for kDepthAim levels as long as that leaves a median tree of
-    // this many triangles ten levels of slack (dragon 100 k: depth 31 -> 27, render 14.8 -> 13.2 ms; with less slack the
-    // forced median splits cost more than the fifth workgroup brings: 1.6 M triangles at 27 levels 22.4 ms against 20.5
-    // at 29-32). Development override: TRH_LBVH_DEPTH.
-    int depth_limit = std::min(bvh::kMaxDepth, std::max(kDepthAim, levels_needed((uint32_t)n) + 10));
-    if (const char* e = getenv("TRH_LBVH_DEPTH")) depth_limit = std::max(levels_needed((uint32_t)n) + 1, std::min(bvh::kMaxDepth, atoi(e)));
+    const unsigned int first_count = (unsigned int)n_seeds;
+    LB_TRY(hipMemcpyAsync(d_counts + 1, &first_count, sizeof(first_count), hipMemcpyHostToDevice, stream));
+    if (top_depth) LB_TRY(hipMemcpyAsync(&d_stats->max_depth, &top_depth, sizeof(top_depth), hipMemcpyHostToDevice, stream));
     for (int depth = 1; depth <= bvh::kMaxDepth + 1; ++depth) {
-        const size_t bound = depth > 27 ? n : std::min<size_t>(n, (size_t)1 << (depth - 1));
-        hipLaunchKernelGGL(k_level, dim3((unsigned)((bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_items_a, (int)bound, depth, depth_limit, d_keys_sorted, d_tris, d_prim,
+        // (generation `depth` of the work queue: with seeds the records of one generation sit at different tree depths)
+        const size_t bound = depth > 27 ? n : std::min<size_t>(n, n_seeds << (depth - 1));
+        hipLaunchKernelGGL(k_level, dim3((unsigned)((bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_items_a, (int)bound, depth_limit, d_keys_sorted, d_tris, d_prim,
                            d_items_b, d_counts + depth, d_counts + depth + 1, d_stats, d_parent, d_child, d_live, d_leaf_box, d_node_box, d_arrived, d_root);
         LB_TRY(hipGetLastError());
         std::swap(d_items_a, d_items_b);
