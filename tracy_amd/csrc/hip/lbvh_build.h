@@ -4,10 +4,10 @@
 // and its CUDA module has no acceleration structure at all (cuda_trace.cu:22-46). The default builder
 // of this module is the host-side binned-SAH build (bvh_builder.h); this is the alternative for
 // scenes whose start-up time matters more than traversal speed (1.6 M triangles in 30 ms instead of
-// 320 ms; the render is 18-25 % slower): a linear BVH built on the GPU -- 63-bit Morton codes of the
+// 320 ms; the render is 5-17 % slower): a linear BVH built on the GPU -- 63-bit Morton codes of the
 // triangle centroids, one radix sort, a top-down pass per tree level that splits every range where
 // its highest differing code bit flips (with the host builder's depth guard), a bottom-up box fit,
-// ranges of <= 4 triangles as leaves, records compacted and emitted directly in the two formats the
+// ranges of <= 2 triangles as leaves, records compacted and emitted directly in the two formats the
 // kernels traverse (bvh_builder.h). Round 2: the UPPER levels, where the Morton order clusters badly,
 // are built with binned SAH over the boxes of <= 32768 Morton clusters (a few hundred KB to the host
 // and back, a few ms on one host thread): 45 -> 34 box tests per ray on the dragon. The arrays stay in

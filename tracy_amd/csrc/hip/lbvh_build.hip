@@ -11,12 +11,12 @@
 //                 the codes are equal or the remaining depth budget demands it (the depth guard of the host
 //                 builder: a Morton tree of a scene with one dense object in a large room is otherwise 40+
 //                 levels deep); the inner node is stored at its split position, which is unique, so the
-//                 layout does not depend on the order the work queue fills. A range of <= 4 triangles is a
+//                 layout does not depend on the order the work queue fills. A range of <= 2 triangles is a
 //                 leaf: its thread computes the box and walks up; the second thread to arrive at a node
 //                 merges the child boxes (acquire/release counter per node)
 //   scan          exclusive sum over the created nodes = compacted record index (the root is moved to record 0)
 //   k_emit        64-byte fp32 and 32-byte fp16 records (layouts in bvh_builder.h), boxes padded and rounded
-//                 outward exactly as the host builder does; sub-trees of <= 4 triangles become leaf links
+//                 outward exactly as the host builder does; sub-trees of <= 2 triangles become leaf links
 //   k_triangles   48-byte Moller-Trumbore records in leaf (= sorted) order
 #include "lbvh_build.h"
 
@@ -36,7 +36,12 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kLinkUnknown = (int)0x80000000;   // k_scatter_top: a child link the linear build fills in
 constexpr int kDepthAim = 27;             // see build(): the depth the guard aims for
-constexpr uint32_t kLeafMax = 4;          // triangles per collapsed leaf (the link format allows bvh::kMaxLeafSize = 8)
+// triangles per leaf (the link format allows bvh::kMaxLeafSize = 8). Swept with the SAH top tree in place (64 spp per launch,
+// dragon / spheres / dragon 400 k): 1: 12.00 / 7.47 / 16.0 ms, 2: 11.54 / 7.18 / 13.8, 3: 11.66 / 7.28, 4: 11.91 / 7.52 / 15.5, 6: 13.02 / 7.92
+#ifndef TRH_LBVH_LEAF
+#define TRH_LBVH_LEAF 2
+#endif
+constexpr uint32_t kLeafMax = TRH_LBVH_LEAF;
 constexpr float kCostTraverse = 0.5f;     // same constants as the host builder: sah_cost is comparable
 constexpr float kCostIntersect = 1.0f;
 
