@@ -273,9 +273,35 @@ DEVFN void trav_inner(const DevScene& sc, V3 o, Trav& tv, int* __restrict__ stac
     tv.top += (h0 && h1) ? TRH_BLOCK : (any ? 0 : -TRH_BLOCK);
 }
 
-// ONE triangle of the current leaf: Moller-Trumbore on a 48-byte record (collision.h:33-74), then
-// advance inside the leaf link ((first + 1) << 4 | (count - 1)) or pop when the leaf is used up.
-// Precondition: tv.node < -1.
+// Moller-Trumbore on one 48-byte record (collision.h:33-74) and the candidate rule; p = leaf-order primitive index.
+// The record may sit in vector registers (trav_leaf: every lane its own triangle) or in scalar registers
+// (trav_packet: one triangle for the whole wave).
+DEVFN void tri_test(const DevScene& sc, V3 o, V3 d, float4 r0, float4 r1, float4 r2, uint32_t p, Hit& hit) {
+    const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z);
+    const uint32_t id = __float_as_uint(r0.w);
+    const V3 pvec = cross_f(d, e2);
+    const V3 tvec = o - v0;
+    const float det = dot_f(e1, pvec);
+    const float u = dot_f(tvec, pvec);
+    const V3 qvec = cross_f(tvec, e1);
+    const float v = dot_f(d, qvec);
+    // collision.h:44,51,59 evaluated without short-circuit branches
+    const bool ok = !(det < EPS) & !(u < EPS) & !(u > det) & !(v < EPS) & !(u + v > det);
+    if (ok) {
+        const float rdet = 1.f / det;
+        const float t = dot_f(e2, qvec) * rdet;
+        if (accept_candidate(sc, o, d, t, id, hit)) {
+            hit.t = t;
+            hit.u = u * rdet;
+            hit.v = v * rdet;
+            hit.prim = (int)p;
+            hit.id = id;
+        }
+    }
+}
+
+// ONE triangle of the current leaf, then advance inside the leaf link ((first + 1) << 4 | (count - 1)) or pop
+// when the leaf is used up. Precondition: tv.node < -1.
 template <bool STATS>
 DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__ stack, Counters& cnt) {
     const uint32_t bits = ~(uint32_t)tv.node;
@@ -290,31 +316,117 @@ DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__
         const float4 r1 = rec[1];
         const float4 r2 = rec[2];
         if (STATS) { cnt.tri_tests += 1; if (first_active_lane()) cnt.w_leaf += 1; }
-        const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z);
-        const uint32_t id = __float_as_uint(r0.w);
-        const V3 pvec = cross_f(d, e2);
-        const V3 tvec = o - v0;
-        const float det = dot_f(e1, pvec);
-        const float u = dot_f(tvec, pvec);
-        const V3 qvec = cross_f(tvec, e1);
-        const float v = dot_f(d, qvec);
-        // collision.h:44,51,59 evaluated without short-circuit branches
-        const bool ok = !(det < EPS) & !(u < EPS) & !(u > det) & !(v < EPS) & !(u + v > det);
-        if (ok) {
-            const float rdet = 1.f / det;
-            const float t = dot_f(e2, qvec) * rdet;
-            if (accept_candidate(sc, o, d, t, id, tv.hit)) {
-                tv.hit.t = t;
-                tv.hit.u = u * rdet;
-                tv.hit.v = v * rdet;
-                tv.hit.prim = (int)p;
-                tv.hit.id = id;
-            }
-        }
+        tri_test(sc, o, d, r0, r1, r2, p, tv.hit);
     }
     // (reading the stack top ahead, as trav_inner does, was measured here too: no gain, a leaf pops only once per leaf)
     if ((bits & 15u) > 1u) tv.node = (int)~(bits + 15u);
     else trav_pop(tv);
+}
+
+// ------------------------------------------------------------------ packet traversal (coherent rays)
+// The 64 rays of a wave walk the tree TOGETHER: one wave-uniform node index, one stack for the wave (64 entries in
+// the lanes of one VGPR, v_writelane / v_readlane), records and triangles fetched by SCALAR loads (one 32-byte request
+// per step for the whole wave instead of 128 vector-L1 requests) and used as scalar operands of the lane's slab and
+// Moller-Trumbore arithmetic. A subtree is entered when ANY lane's ray meets its box, the nearer child first by the
+// majority of the lanes that meet both. Every lane tests every triangle of every leaf the wave visits; a triangle in
+// a box its own ray misses cannot be hit (the box holds the triangle), so each lane ends with the same nearest hit as
+// its own traversal would find (same candidate rule, accept_candidate). Meant for camera rays of one pixel or of a few
+// neighbouring pixels: the union of their walks is hardly larger than each walk, and no lane waits for another.
+typedef uint32_t U32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t U32x16 __attribute__((ext_vector_type(16)));
+typedef float F32x4 __attribute__((ext_vector_type(4)));
+#define TRH_SCALAR_AS __attribute__((address_space(4)))   // constant address space: a wave-uniform address becomes s_load
+
+// lane `index` of a VGPR as one element of a wave-uniform array (index and value wave-uniform)
+DEVFN uint32_t write_lane(uint32_t v, uint32_t index, uint32_t value) {
+    // v_writelane_b32 takes one scalar register besides M0 (constant bus): the lane select goes through M0
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
+                 : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane((int)value)), "s"(__builtin_amdgcn_readfirstlane((int)index)) : "m0");
+    return v;
+}
+DEVFN uint32_t read_lane(uint32_t v, uint32_t index) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)index); }
+
+template <bool N16>
+DEVFN void trav_packet(const DevScene& sc, V3 o, V3 d, bool valid, Hit& hit) {
+    const float lim = sc.frame_inv_lim;
+    V3 inv = mk(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -lim, lim), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -lim, lim),
+                __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -lim, lim));
+    const V3 oi = mk((o.x - sc.frame_c[0]) * inv.x, (o.y - sc.frame_c[1]) * inv.y, (o.z - sc.frame_c[2]) * inv.z);
+    inv = inv * sc.frame_sinv;
+    const uint32_t selx = (__float_as_uint(d.x) >> 31) ? 0x01000302u : 0x03020100u;
+    const uint32_t sely = (__float_as_uint(d.y) >> 31) ? 0x01000302u : 0x03020100u;
+    const uint32_t selz = (__float_as_uint(d.z) >> 31) ? 0x01000302u : 0x03020100u;
+    hit.t = 3.402823466e+38f;
+    hit.u = hit.v = 0.f;
+    hit.prim = -1;
+    hit.id = TRH_MISS_ID;
+    const bool act = valid && !(d.x != d.x);   // NaN direction: a miss (trav_begin)
+    uint32_t vstack = 0;                        // lane i = stack entry i
+    uint32_t sp = 0;
+    int node = __ballot(act) != 0ull ? 0 : -1;
+    for (;;) {
+        if (node >= 0) {
+            float tmin0, tmax0, tmin1, tmax1;
+            int c0, c1;
+            if (N16) {
+                const U32x8 q = *reinterpret_cast<const TRH_SCALAR_AS U32x8*>(reinterpret_cast<uintptr_t>(sc.nodes16) + ((size_t)(uint32_t)node << 5));
+                const H2 hx0 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(q[0], q[0], selx)), hy0 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(q[1], q[1], sely));
+                const H2 hx1 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(q[2], q[2], selx)), hy1 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(q[3], q[3], sely));
+                const H2 hz0 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(q[4], q[4], selz)), hz1 = __builtin_bit_cast(H2, __builtin_amdgcn_perm(q[5], q[5], selz));
+                const float anx = __builtin_fmaf((float)hx0.x, inv.x, -oi.x), afx = __builtin_fmaf((float)hx0.y, inv.x, -oi.x);
+                const float any = __builtin_fmaf((float)hy0.x, inv.y, -oi.y), afy = __builtin_fmaf((float)hy0.y, inv.y, -oi.y);
+                const float anz = __builtin_fmaf((float)hz0.x, inv.z, -oi.z), afz = __builtin_fmaf((float)hz0.y, inv.z, -oi.z);
+                const float bnx = __builtin_fmaf((float)hx1.x, inv.x, -oi.x), bfx = __builtin_fmaf((float)hx1.y, inv.x, -oi.x);
+                const float bny = __builtin_fmaf((float)hy1.x, inv.y, -oi.y), bfy = __builtin_fmaf((float)hy1.y, inv.y, -oi.y);
+                const float bnz = __builtin_fmaf((float)hz1.x, inv.z, -oi.z), bfz = __builtin_fmaf((float)hz1.y, inv.z, -oi.z);
+                tmin0 = fmaxf(fmaxf(anx, any), fmaxf(anz, 0.f));
+                tmax0 = fminf(fminf(afx, afy), fminf(afz, hit.t));
+                tmin1 = fmaxf(fmaxf(bnx, bny), fmaxf(bnz, 0.f));
+                tmax1 = fminf(fminf(bfx, bfy), fminf(bfz, hit.t));
+                c0 = (int)q[6]; c1 = (int)q[7];
+            } else {
+                const U32x16 q = *reinterpret_cast<const TRH_SCALAR_AS U32x16*>(reinterpret_cast<uintptr_t>(sc.nodes) + ((size_t)(uint32_t)node << 6));
+                const float ax0 = __builtin_fmaf(__uint_as_float(q[0]), inv.x, -oi.x), ax1 = __builtin_fmaf(__uint_as_float(q[1]), inv.x, -oi.x);
+                const float ay0 = __builtin_fmaf(__uint_as_float(q[2]), inv.y, -oi.y), ay1 = __builtin_fmaf(__uint_as_float(q[3]), inv.y, -oi.y);
+                const float az0 = __builtin_fmaf(__uint_as_float(q[8]), inv.z, -oi.z), az1 = __builtin_fmaf(__uint_as_float(q[9]), inv.z, -oi.z);
+                const float bx0 = __builtin_fmaf(__uint_as_float(q[4]), inv.x, -oi.x), bx1 = __builtin_fmaf(__uint_as_float(q[5]), inv.x, -oi.x);
+                const float by0 = __builtin_fmaf(__uint_as_float(q[6]), inv.y, -oi.y), by1 = __builtin_fmaf(__uint_as_float(q[7]), inv.y, -oi.y);
+                const float bz0 = __builtin_fmaf(__uint_as_float(q[10]), inv.z, -oi.z), bz1 = __builtin_fmaf(__uint_as_float(q[11]), inv.z, -oi.z);
+                tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.f));
+                tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), hit.t));
+                tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.f));
+                tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), hit.t));
+                c0 = (int)q[12]; c1 = (int)q[13];
+            }
+            const bool h0 = act & (tmin0 <= tmax0);
+            const bool h1 = act & (tmin1 <= tmax1);
+            const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+            if ((b0 != 0ull) & (b1 != 0ull)) {
+                const unsigned long long sw = __ballot(h1 & (!h0 | (tmin1 < tmin0)));   // lanes for which child 1 is the nearer (or only) hit
+                const bool first1 = 2u * (uint32_t)__popcll(sw) > (uint32_t)__popcll(b0 | b1);
+                vstack = write_lane(vstack, sp, (uint32_t)(first1 ? c0 : c1));
+                sp += 1u;
+                node = first1 ? c1 : c0;
+            } else {
+                node = b0 != 0ull ? c0 : (b1 != 0ull ? c1 : -1);
+            }
+        } else if (node < -1) {
+            const uint32_t bits = ~(uint32_t)node;
+            const uint32_t first = bits >> 4, count = bits & 15u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t p = first + k;
+                const TRH_SCALAR_AS F32x4* rec = reinterpret_cast<const TRH_SCALAR_AS F32x4*>(reinterpret_cast<uintptr_t>(sc.tris) + (size_t)p * 48u);
+                const F32x4 s0 = rec[0], s1 = rec[1], s2 = rec[2];
+                if (act) tri_test(sc, o, d, make_float4(s0[0], s0[1], s0[2], s0[3]), make_float4(s1[0], s1[1], s1[2], s1[3]), make_float4(s2[0], s2[1], s2[2], s2[3]), p, hit);
+            }
+            node = -1;
+        }
+        if (node == -1) {   // pop
+            if (sp == 0u) break;
+            sp -= 1u;
+            node = (int)read_lane(vstack, sp);
+        }
+    }
 }
 
 template <bool STATS, bool N16>

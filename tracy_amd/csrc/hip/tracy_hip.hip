@@ -354,6 +354,208 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
     flush_counters<STATS>(cnt, counters);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_megakernel_ab: the megakernel with the camera rays taken out of the lane scheduler (round 3; default).
+//
+// A tile's items run sample-major, so 64 consecutive items are camera rays through ONE pixel (or two neighbours): they
+// walk the same nodes and hit the same few triangles. The wave therefore alternates between two phases per tile:
+//   * camera phase: 64 items at a time -- generate, ONE packet traversal for the whole wave (trav_packet: wave-uniform
+//     node index and stack, records and triangles by scalar loads, every lane busy in every instruction), shade,
+//     roulette. Paths that go on are appended to the wave's bounce queue in HBM/L2 (48 bytes: origin, direction,
+//     throughput, RNG state, bounce | pixel), ballot + mbcnt compaction, coalesced float4 stores;
+//   * bounce phase: the lane scheduler of k_megakernel (vote between inner steps and triangle steps, LDS stack columns,
+//     shade + refill when refill_thresh lanes wait), refilled from the queue instead of from generate().
+// The queue holds rp.pq_cap paths per wave. The camera phase ends when the queue is full or the tile's items are used up;
+// the bounce phase ends when the queue is empty and every path is finished -- or, while camera paths are left, as soon as
+// park_limit or fewer lanes are still busy: those finish their current RAY, are shaded, and go back to the queue
+// ("parked") instead of keeping 64 lanes waiting for the longest path.
+// Same sample set, same arithmetic per path as k_megakernel; only the order of a pixel's float additions differs.
+// ---------------------------------------------------------------------------------------
+template <bool N16>
+__global__ __launch_bounds__(TRH_BLOCK) __attribute__((amdgpu_waves_per_eu(TRH_MEGA_WAVES_PER_EU, TRH_MEGA_WAVES_PER_EU)))
+void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
+    extern __shared__ int s_dyn[];
+    s_dyn[threadIdx.x] = -1;   // sentinel row of this lane's stack column (dev_trace.h)
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t P_log2 = rp.tile_w_log2 + rp.tile_h_log2;
+    const uint32_t P = 1u << P_log2;
+    const uint32_t acc_stride = P * 3u + 1u;
+    float* const wacc = reinterpret_cast<float*>(s_dyn + rp.stack_entries * TRH_BLOCK) + wave_in_block * (acc_stride * rp.acc_copies);   // wave-uniform
+    float4* const qa = rp.pq + (size_t)(blockIdx.x * (uint32_t)TRH_WAVES_PER_BLOCK + wave_in_block) * 3u * rp.pq_cap;                   // wave-uniform
+    float4* const qb = qa + rp.pq_cap;
+    float4* const qc = qb + rp.pq_cap;
+    const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
+    const uint32_t total = P * rp.spp_count;   // items per tile
+    Counters cnt = {};
+
+    for (;;) {
+        const uint32_t lane = fresh_lane_id();
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(tile_counter, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= ntiles) break;  // wave-uniform exit: every wave reaches it
+        if (rp.tile_order) tile = __builtin_amdgcn_readfirstlane(rp.tile_order[tile]);   // expensive tiles first (tile_order.h)
+        const unsigned long long t_tile = rp.tile_cost ? __builtin_readcyclecounter() : 0ull;
+        const int tile_x0 = (int)((tile % rp.tiles_x) << rp.tile_w_log2);
+        const int tile_y0 = (int)((tile / rp.tiles_x) << rp.tile_h_log2);
+        for (uint32_t i = lane; i < acc_stride * rp.acc_copies; i += 64) wacc[i] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+
+        uint32_t next = 0;                  // wave-uniform: next item of this tile without a camera ray
+        uint32_t q_head = 0, q_tail = 0;    // wave-uniform: the queue holds the entries [q_head, q_tail)
+        bool camera_phase = true;           // wave-uniform
+        bool park = false;                  // wave-uniform: the bounce phase is being wound up (see above)
+        PathState ps;
+        ps.o = ps.d = ps.throughput = ps.radiance = mk(0.f, 0.f, 0.f);
+        ps.rng = 0;
+        ps.bounce = 0;
+        Trav tv;
+        tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
+        tv.selx = tv.sely = tv.selz = 0x03020100u;
+        tv.node = -1;
+        tv.top = s_dyn + (wave_in_block * 64u + lane);
+        tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
+        uint32_t pix = 0;           // pixel-in-tile of the path this lane works on
+        bool has_path = false;      // the lane holds a path (traversing, waiting to be shaded, or waiting to be queued)
+
+        for (;;) {
+            // ---- shade the lanes whose ray is finished
+            if (has_path && !trav_active(tv)) {
+                const bool cont = shade<false>(sc, ps, tv.hit, cnt);
+                if (ps.radiance.x != 0.f || ps.radiance.y != 0.f || ps.radiance.z != 0.f) {
+                    float* const lane_acc = wacc + ((fresh_lane_id() & (rp.acc_copies - 1u)) * acc_stride + pix * 3u);
+                    __hip_atomic_fetch_add(&lane_acc[0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&lane_acc[1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&lane_acc[2], ps.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                ps.radiance = mk(0.f, 0.f, 0.f);
+                if (!cont) has_path = false;
+                else if (!(camera_phase | park)) trav_begin(sc, tv, ps.o, ps.d, stack_column(s_dyn, tv.top));
+                // else: the lane keeps its path without a ray; it goes to the queue right below
+            }
+            if (camera_phase | park) {
+                // ---- queue the paths that go on: ballot + prefix compaction, three coalesced float4 stores
+                const bool push = has_path && !trav_active(tv);
+                const unsigned long long pmask = __ballot(push);
+                if (pmask != 0ull) {
+                    if (push) {
+                        const uint32_t idx = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
+                        qa[idx] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+                        qb[idx] = make_float4(ps.d.y, ps.d.z, ps.throughput.x, ps.throughput.y);
+                        qc[idx] = make_float4(ps.throughput.z, __uint_as_float(ps.rng), __uint_as_float((ps.bounce << 8) | pix), 0.f);
+                        has_path = false;
+                    }
+                    q_tail += (uint32_t)__popcll(pmask);
+                }
+            }
+            if (camera_phase) {
+                if (next < total && q_tail + 64u <= rp.pq_cap) {
+                    // ---- 64 camera rays: generate, one packet traversal; the loop's head shades them
+                    const uint32_t item = next + fresh_lane_id();
+                    next += 64u;
+                    bool valid = item < total;
+                    if (valid) {
+                        pix = __umulhi(item, rp.spp_magic);
+                        uint32_t sample = item - pix * rp.spp_count;
+                        if (sample >= rp.spp_count) { pix += 1u; sample -= rp.spp_count; }
+                        sample += rp.spp_begin;
+                        const int px = tile_x0 + (int)(pix & ((1u << rp.tile_w_log2) - 1u));
+                        const int py = tile_y0 + (int)(pix >> rp.tile_w_log2);
+                        valid = px < sc.width && py < sc.height;   // pixel outside the frame (partial edge tile): the item is dropped
+                        if (valid) generate(sc, ps, px, py, sample, rp.seed32);
+                    }
+                    trav_packet<N16>(sc, ps.o, ps.d, valid, tv.hit);
+                    has_path = valid;
+                    continue;   // tv.node == -1 in every lane here
+                }
+                camera_phase = false;
+                // the queue stores above are complete before the bounce phase loads them (same CU, same L1: workgroup scope)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            }
+            // ---- bounce phase refill: idle lanes take the next queue entries, in lane order
+            if (!park && q_head < q_tail) {
+                const bool want = !has_path;
+                const unsigned long long wmask = __ballot(want);
+                if (wmask != 0ull) {
+                    if (want) {
+                        const uint32_t idx = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
+                        if (idx < q_tail) {
+                            const float4 a = qa[idx], b = qb[idx], c = qc[idx];
+                            ps.o = mk(a.x, a.y, a.z);
+                            ps.d = mk(a.w, b.x, b.y);
+                            ps.throughput = mk(b.z, b.w, c.x);
+                            ps.rng = __float_as_uint(c.y);
+                            const uint32_t bp = __float_as_uint(c.z);
+                            ps.bounce = bp >> 8;
+                            pix = bp & 255u;
+                            trav_begin(sc, tv, ps.o, ps.d, stack_column(s_dyn, tv.top));
+                            has_path = true;
+                        }
+                    }
+                    q_head += (uint32_t)__popcll(wmask);
+                    if (q_head > q_tail) q_head = q_tail;
+                }
+            }
+            const uint32_t nP = (uint32_t)__popcll(__ballot(has_path));   // constant during the traversal phase
+            if (__ballot(trav_active(tv)) == 0ull) {
+                if (nP != 0u) continue;                 // paths whose ray ended at once (NaN direction): shade them
+                if (!park && q_head < q_tail) continue; // (every lane is idle here, so the refill above has emptied the queue)
+                if (next >= total) break;               // tile done
+                // back to the camera phase; parked paths stay at the head of the queue
+                if (!park) q_head = q_tail = 0u;
+                park = false;
+                camera_phase = true;
+                continue;
+            }
+            // Wind the bounce phase up? Only while camera paths are left: at the end of the tile the paths run to their end.
+            if (!park && q_head >= q_tail && next < total && nP <= rp.park_limit) {
+                park = true;
+                q_head = q_tail = 0u;
+            }
+            // ---- traverse until enough lanes are waiting again (k_megakernel's vote loop)
+            const uint32_t wait_limit = park ? nP : (nP < rp.refill_thresh ? nP : rp.refill_thresh);
+            __builtin_amdgcn_s_setprio(3);
+            for (;;) {
+                const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
+                const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
+                if (nP - (nI + nL) >= wait_limit) break;
+                if (nI * 4u >= nL * rp.sched_beta4) {
+#pragma unroll
+                    for (int r = 0; r < TRH_INNER_REPEAT; ++r)
+                        if (tv.node >= 0) trav_inner<false, N16>(sc, ps.o, tv, nullptr, cnt);
+                } else {
+                    if (tv.node < -1) trav_leaf<false>(sc, ps.o, ps.d, tv, nullptr, cnt);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // ---- flush the tile: plain read-modify-write, the tile belongs to this wave
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = fresh_lane_id(); i < P; i += 64) {
+            const int px = tile_x0 + (int)(i & ((1u << rp.tile_w_log2) - 1u));
+            const int py = tile_y0 + (int)(i >> rp.tile_w_log2);
+            if (px < sc.width && py < sc.height) {
+                const size_t p = (size_t)py * sc.width + px;
+                float4 a = accum[p];
+                float r = 0.f, g = 0.f, b = 0.f;
+                for (uint32_t k = 0; k < rp.acc_copies; ++k) {   // fixed order: run-to-run identical
+                    r += wacc[k * acc_stride + i * 3 + 0];
+                    g += wacc[k * acc_stride + i * 3 + 1];
+                    b += wacc[k * acc_stride + i * 3 + 2];
+                }
+                a.x += r; a.y += g; a.z += b; a.w += (float)rp.spp_count;
+                accum[p] = a;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (rp.tile_cost && fresh_lane_id() == 0u) {
+            const unsigned long long dt = __builtin_readcyclecounter() - t_tile;
+            rp.tile_cost[tile] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+        }
+    }
+    flush_counters<false>(cnt, counters);
+}
+
 template <bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) void k_primary_hits(DevScene sc, uint32_t* __restrict__ ids, float* __restrict__ t_out, float2* __restrict__ uv_out) {
     __shared__ int s_stack[(TRH_STACK_SIZE + 1) * TRH_BLOCK];
@@ -520,6 +722,12 @@ struct trh_context {
     uint32_t refill_thresh = 40;   // swept 16..48 with the cost-ordered 2048-item tiles
     uint32_t sched_beta4 = 6;
     size_t lds_pad = 0;
+    // k_megakernel_ab: the bounce queues of the resident waves (allocated at the first launch, freed with the scene)
+    bool camera_packets = true;    // TRH_CAMERA_PACKETS=0: the round-2 kernel (k_megakernel) for every launch
+    float4* pq = nullptr;
+    size_t pq_waves = 0;           // wave slots the allocation holds
+    uint32_t pq_cap = 4096;        // entries per wave
+    uint32_t park_limit = 40;
     // device buffer of the parity probes (trh_primary_hits / trh_sample_radiance), grown on demand, freed at shutdown
     void* probe_buf = nullptr;
     size_t probe_bytes = 0;
@@ -550,6 +758,8 @@ int free_scene(trh_context* c) {
     c->wf_allocs.clear();
     c->wf = WfBuffers{};
     c->wf_item_capacity = 0;
+    c->pq = nullptr;       // (in c->allocs)
+    c->pq_waves = 0;
     c->accum = nullptr;
     c->accum_internal = nullptr;
     c->resolved = nullptr;
@@ -681,12 +891,38 @@ int launch_megakernel_tiled(trh_context* c, TileState& ts, RenderParams rp, uint
     while (rp.acc_copies > 1u && (acc_bytes(rp.acc_copies) > 4u * 3200u || (stack_bytes + acc_bytes(rp.acc_copies)) * (unsigned)TRH_MEGA_WAVES_PER_EU > 160u * 1024u)) rp.acc_copies >>= 1;
     size_t lds = stack_bytes + acc_bytes(rp.acc_copies);
     lds += c->lds_pad;   // development knob: lowers occupancy to measure latency sensitivity
+    // Camera rays as packets + bounce queue (k_megakernel_ab) for every launch of the context's own tile state; the
+    // instrumented kernel counts the per-ray work of the lane scheduler (the algorithmic figure of the roofline), and
+    // trh_render_noalloc (a tile state in the static scratch) has no queue memory: both run k_megakernel.
+    const bool ab = !STATS && c->camera_packets && &ts == &c->ts;
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS, N16>, TRH_BLOCK, lds));
+    if (ab) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel_ab<N16>, TRH_BLOCK, lds));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS, N16>, TRH_BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     const int grid = per_cu * c->num_cus;
+    if (ab) {
+        const size_t waves = (size_t)grid * TRH_WAVES_PER_BLOCK;
+        if (c->pq_waves < waves) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->pq) {
+                c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void*)c->pq), c->allocs.end());
+                (void)hipFree(c->pq);
+                c->pq = nullptr;
+                c->pq_waves = 0;
+            }
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, waves * 3u * c->pq_cap * sizeof(float4)));
+            c->allocs.push_back(p);
+            c->pq = (float4*)p;
+            c->pq_waves = waves;
+        }
+        rp.pq = c->pq;
+        rp.pq_cap = c->pq_cap;
+        rp.park_limit = c->park_limit;
+    }
     HIP_TRY(hipMemsetAsync(ts.tile_counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((k_megakernel<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, ts.tile_counter);
+    if (ab) hipLaunchKernelGGL((k_megakernel_ab<N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, ts.tile_counter);
+    else hipLaunchKernelGGL((k_megakernel<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, ts.tile_counter);
     HIP_TRY(hipGetLastError());
     if (ordered) {
         const int e = tile_order::sort_by_cost(ts.cost, ts.order, ts.count, ts.keys, ts.keys_sorted, ts.iota, ts.sort_temp, ts.sort_temp_bytes, c->stream);
@@ -966,6 +1202,15 @@ int trh_init(int device, trh_context** ctx_out) {
         if (v >= 8 && v <= 26) c->wf_pool_limit = 1u << v;
     }
     if (const char* e = getenv("TRH_LDS_PAD")) c->lds_pad = (size_t)atoi(e);
+    if (const char* e = getenv("TRH_CAMERA_PACKETS")) c->camera_packets = atoi(e) != 0;   // development knob: 0 = k_megakernel for every launch
+    if (const char* e = getenv("TRH_PQ_CAP")) {             // development knob: bounce-queue entries per wave
+        const int v = atoi(e);
+        if (v >= 128 && v <= (1 << 20)) c->pq_cap = ((uint32_t)v + 63u) & ~63u;
+    }
+    if (const char* e = getenv("TRH_PARK_LIMIT")) {         // development knob
+        const int v = atoi(e);
+        if (v >= 0 && v <= 64) c->park_limit = (uint32_t)v;
+    }
     if (const char* e = getenv("TRH_TILE_FEEDBACK")) c->tile_feedback = atoi(e) != 0;   // development knob: 0 = raster order always
     if (const char* e = getenv("TRH_BUILDER")) c->builder = strcmp(e, "lbvh") == 0 ? TRH_BUILDER_DEVICE_LBVH : TRH_BUILDER_HOST_SAH;   // default builder of this context
     if (const char* e = getenv("TRH_SCHED_BETA4")) {     // development knob
