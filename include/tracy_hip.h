@@ -95,11 +95,14 @@ typedef struct trh_scene_desc {
     uint32_t flags;              /* TRH_FLAG_* */
 } trh_scene_desc;
 
-/* Which kernel pipeline trh_render uses. Both produce the same per-sample paths. */
+/* Which kernel pipeline trh_render uses. All produce the same per-sample paths. */
 typedef enum trh_pipeline {
-    TRH_PIPELINE_MEGAKERNEL = 0, /* persistent waves, wave-local path scheduler (default) */
-    TRH_PIPELINE_WAVEFRONT = 1,  /* generate / extend / shade queues, wave64 ballot compaction */
-    TRH_PIPELINE_MEGAKERNEL_SIMPLE = 2  /* first-generation kernel (lane == pixel), kept for A/B */
+    TRH_PIPELINE_MEGAKERNEL = 0, /* default: persistent waves; every wave runs camera / traverse / shade phases over its own
+                                    ring of paths (camera rays as wave packets, bounce rays by the lane scheduler) */
+    TRH_PIPELINE_WAVEFRONT = 1,  /* generate / extend / shade queues in HBM, one kernel per stage, wave64 ballot compaction */
+    TRH_PIPELINE_MEGAKERNEL_SIMPLE = 2, /* first-generation kernel (lane == pixel), kept for A/B */
+    TRH_PIPELINE_MEGAKERNEL_LANES = 3   /* round 2's default: every lane runs its own path from camera ray to last bounce
+                                           (needs no ring memory: the kernel of trh_render_noalloc and of trh_render_stats) */
 } trh_pipeline;
 
 typedef struct trh_context trh_context;   /* opaque; one per HIP device */
@@ -191,13 +194,15 @@ int trh_render_stats(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, u
 
 /* trh_render for callers that cannot allocate. NO COUNTERPART IN THE REFERENCE: it exists for hosts that
  * run under HIP graph capture, in tight serving loops or in harnesses that forbid hipMalloc. Same samples, same
- * kernels and the same launch sequence as trh_render on a context that has no tile order yet (every call of
- * >= 16 spp traces its first sample as a launch of its own), but the launch scratch -- the tile counter the
+ * kernels and the same launch sequence as trh_render with TRH_PIPELINE_MEGAKERNEL_LANES on a context that has no tile
+ * order yet (every call of >= 16 spp traces its first sample as a launch of its own): bit-equal to that; equal to the
+ * default pipeline up to the order of a pixel's float additions (the default pipeline's ring of paths is hipMalloc'ed
+ * memory that grows with the launch, so it is not used here). The launch scratch -- the tile counter the
  * persistent waves pull from, and the cost / order / key arrays and the sort's temporary storage of the
- * cost-ordered tile hand-out -- lives in a file-scope __device__ array of 6.25 MiB that every GPU the library
+ * cost-ordered tile hand-out -- lives in a file-scope __device__ array of 9.25 MiB that every GPU the library
  * runs on holds until the process ends, instead of in hipMalloc'ed memory. The call performs no hipMalloc,
  * hipFree, event creation or other allocating routine and records no launch timing (trh_stats.kernel_ms /
- * launches do not count it; rays and samples do). Limits: megakernel pipeline only (TRH_ERR_STATE otherwise),
+ * launches do not count it; rays and samples do). Limits: TRH_PIPELINE_MEGAKERNEL or _LANES set (TRH_ERR_STATE otherwise),
  * <= 65536 spp per call, and at most 262144 tiles (1080p and 4K frames at >= 8 spp per call fit; TRH_ERR_LIMIT
  * names the tile count otherwise). All contexts on one GPU share that GPU's array: calls that overlap on one
  * GPU (two contexts, two threads) race; calls on different GPUs do not. */

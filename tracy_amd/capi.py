@@ -17,6 +17,7 @@ TRH_FLAG_RUSSIAN_ROULETTE = 1
 TRH_PIPELINE_MEGAKERNEL = 0
 TRH_PIPELINE_WAVEFRONT = 1
 TRH_PIPELINE_MEGAKERNEL_SIMPLE = 2
+TRH_PIPELINE_MEGAKERNEL_LANES = 3
 TRH_TONEMAP_NONE, TRH_TONEMAP_SRGB, TRH_TONEMAP_REINHARD, TRH_TONEMAP_ACES = 0, 1, 2, 3
 TRH_BUILDER_HOST_SAH, TRH_BUILDER_DEVICE_LBVH = 0, 1
 TRH_VIEW_NONE, TRH_VIEW_BASECOLOR, TRH_VIEW_NORMALS, TRH_VIEW_METALNESS, TRH_VIEW_ROUGHNESS, TRH_VIEW_EMISSIVE = 0, 1, 2, 3, 4, 5

@@ -65,11 +65,12 @@ struct RenderParams {
     uint32_t acc_copies;          // LDS accumulator copies per wave (1, 2, 4, 8)
     const uint32_t* tile_order;   // NULL: raster order; else the order the tile counter indexes (tile_order.h)
     uint32_t* tile_cost;          // NULL, or per-tile shader-clock ticks of this launch (input of the next launch's order)
-    // k_megakernel_ab only: the bounce queue. Every resident wave owns 3 arrays of pq_cap float4 (wave slot = blockIdx.x *
-    // TRH_WAVES_PER_BLOCK + wave in block): paths that survived their camera ray wait here for the bounce phase.
+    // k_megakernel_ab only: the wave's ray ring. Every resident wave owns 4 arrays of pq_cap float4 (wave slot = blockIdx.x *
+    // TRH_WAVES_PER_BLOCK + wave in block): three hold a path (origin, direction, throughput, RNG, bounce | pixel), the
+    // fourth the hit of its current ray.
     float4* pq;
-    uint32_t pq_cap;              // entries per wave, a multiple of 64, >= 128
-    uint32_t park_limit;          // bounce phase: with the queue empty and camera paths left, this many (or fewer) live lanes end the phase
+    uint32_t pq_cap;              // entries per wave: a power of two, >= 128
+    uint32_t pq_target;           // the camera phase stops once this many rays are ready to be traversed (<= pq_cap - 64)
 };
 
 // device-side counters, one cache line

@@ -355,23 +355,28 @@ void k_megakernel(DevScene sc, RenderParams rp, float4* __restrict__ accum,
 }
 
 // ---------------------------------------------------------------------------------------
-// k_megakernel_ab: the megakernel with the camera rays taken out of the lane scheduler (round 3; default).
+// k_megakernel_ab: a wavefront path tracer inside every wave (round 3; default pipeline).
 //
-// A tile's items run sample-major, so 64 consecutive items are camera rays through ONE pixel (or two neighbours): they
-// walk the same nodes and hit the same few triangles. The wave therefore alternates between two phases per tile:
-//   * camera phase: 64 items at a time -- generate, ONE packet traversal for the whole wave (trav_packet: wave-uniform
-//     node index and stack, records and triangles by scalar loads, every lane busy in every instruction), shade,
-//     roulette. Paths that go on are appended to the wave's bounce queue in HBM/L2 (48 bytes: origin, direction,
-//     throughput, RNG state, bounce | pixel), ballot + mbcnt compaction, coalesced float4 stores;
-//   * bounce phase: the lane scheduler of k_megakernel (vote between inner steps and triangle steps, LDS stack columns,
-//     shade + refill when refill_thresh lanes wait), refilled from the queue instead of from generate().
-// The queue holds rp.pq_cap paths per wave. The camera phase ends when the queue is full or the tile's items are used up;
-// the bounce phase ends when the queue is empty and every path is finished -- or, while camera paths are left, as soon as
-// park_limit or fewer lanes are still busy: those finish their current RAY, are shaded, and go back to the queue
-// ("parked") instead of keeping 64 lanes waiting for the longest path.
+// k_megakernel lets every lane run its own path from camera ray to last bounce; lanes that finished a ray wait for the
+// divergent shade + refill code until enough of them have gathered (lanes per VALU instruction on the dragon: 0.57,
+// 0.46 on the bounce rays alone). Here a wave splits the work of its tile into three phases over a ring of paths it
+// keeps in global memory (L2-resident: written and read by this wave only, no atomics, no inter-wave traffic):
+//   * camera phase: 64 items at a time (sample-major: camera rays through ONE pixel or two neighbours) -- generate, ONE
+//     packet traversal for the whole wave (trav_packet: wave-uniform node index and stack, records and triangles by
+//     scalar loads, every lane busy in every instruction), shade, roulette; the paths that go on are appended to the
+//     ring (ballot + mbcnt compaction, coalesced float4 stores: origin, direction, throughput, RNG state, bounce | pixel);
+//   * traverse phase: lanes take RAYS from the ring (origin + direction: 32 bytes) and run k_megakernel's vote loop
+//     (inner steps against triangle steps, LDS stack columns). A lane that finishes stores the hit (16 bytes) next to
+//     its path and takes the next ray as soon as refill_thresh lanes are ready to do the same -- no shading in this
+//     loop, no path state in its registers. The phase ends when the ready rays are used up and every lane is done;
+//   * shade phase: the traversed paths, 64 at a time, every lane busy: attribute interpolation, textures, Scatter, sky,
+//     roulette, LDS tile accumulators; survivors go back to the ring as new rays.
+// Queue discipline: ring indices shade_head <= head <= tail (mod pq_cap): [shade_head, head) traversed, waiting to be
+// shaded; [head, tail) ready to be traversed. The camera phase runs while the tile has items, the ring has 64 free
+// entries and fewer than pq_target rays are ready, so that a traverse phase is long against its drain.
 // Same sample set, same arithmetic per path as k_megakernel; only the order of a pixel's float additions differs.
 // ---------------------------------------------------------------------------------------
-template <bool N16>
+template <bool STATS, bool N16>
 __global__ __launch_bounds__(TRH_BLOCK) __attribute__((amdgpu_waves_per_eu(TRH_MEGA_WAVES_PER_EU, TRH_MEGA_WAVES_PER_EU)))
 void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, DevCounters* __restrict__ counters, unsigned int* __restrict__ tile_counter) {
     extern __shared__ int s_dyn[];
@@ -381,12 +386,16 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
     const uint32_t P = 1u << P_log2;
     const uint32_t acc_stride = P * 3u + 1u;
     float* const wacc = reinterpret_cast<float*>(s_dyn + rp.stack_entries * TRH_BLOCK) + wave_in_block * (acc_stride * rp.acc_copies);   // wave-uniform
-    float4* const qa = rp.pq + (size_t)(blockIdx.x * (uint32_t)TRH_WAVES_PER_BLOCK + wave_in_block) * 3u * rp.pq_cap;                   // wave-uniform
+    float4* const qa = rp.pq + (size_t)(blockIdx.x * (uint32_t)TRH_WAVES_PER_BLOCK + wave_in_block) * 4u * rp.pq_cap;                   // wave-uniform
     float4* const qb = qa + rp.pq_cap;
     float4* const qc = qb + rp.pq_cap;
+    float4* const qh = qc + rp.pq_cap;
+    const uint32_t qmask = rp.pq_cap - 1u;
     const uint32_t ntiles = rp.tiles_x * rp.tiles_y;
     const uint32_t total = P * rp.spp_count;   // items per tile
     Counters cnt = {};
+    const unsigned long long t_kernel = STATS ? __builtin_readcyclecounter() : 0ull;
+    if (STATS) cnt.t_start = wall_clock64();
 
     for (;;) {
         const uint32_t lane = fresh_lane_id();
@@ -401,27 +410,22 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
         for (uint32_t i = lane; i < acc_stride * rp.acc_copies; i += 64) wacc[i] = 0.f;
         __builtin_amdgcn_wave_barrier();
 
-        uint32_t next = 0;                  // wave-uniform: next item of this tile without a camera ray
-        uint32_t q_head = 0, q_tail = 0;    // wave-uniform: the queue holds the entries [q_head, q_tail)
-        bool camera_phase = true;           // wave-uniform
-        bool park = false;                  // wave-uniform: the bounce phase is being wound up (see above)
+        uint32_t next = 0;                                // wave-uniform: next item of this tile without a camera ray
+        uint32_t shade_head = 0, head = 0, tail = 0;      // wave-uniform ring cursors (free-running, masked on use)
         PathState ps;
         ps.o = ps.d = ps.throughput = ps.radiance = mk(0.f, 0.f, 0.f);
         ps.rng = 0;
         ps.bounce = 0;
-        Trav tv;
-        tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
-        tv.selx = tv.sely = tv.selz = 0x03020100u;
-        tv.node = -1;
-        tv.top = s_dyn + (wave_in_block * 64u + lane);
-        tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
-        uint32_t pix = 0;           // pixel-in-tile of the path this lane works on
-        bool has_path = false;      // the lane holds a path (traversing, waiting to be shaded, or waiting to be queued)
+        Hit hit;
+        hit.t = 0.f; hit.u = hit.v = 0.f; hit.prim = -1; hit.id = TRH_MISS_ID;
+        uint32_t pix = 0;           // pixel-in-tile of the path this lane shades
+        bool has_path = false;      // the lane holds a path whose ray is traced: shade it
 
         for (;;) {
-            // ---- shade the lanes whose ray is finished
-            if (has_path && !trav_active(tv)) {
-                const bool cont = shade<false>(sc, ps, tv.hit, cnt);
+            // ---- shade (camera phase and shade phase end here), then queue the paths that go on
+            const unsigned long long t_phase0 = STATS ? __builtin_readcyclecounter() : 0ull;
+            if (has_path) {
+                const bool cont = shade<STATS>(sc, ps, hit, cnt);
                 if (ps.radiance.x != 0.f || ps.radiance.y != 0.f || ps.radiance.z != 0.f) {
                     float* const lane_acc = wacc + ((fresh_lane_id() & (rp.acc_copies - 1u)) * acc_stride + pix * 3u);
                     __hip_atomic_fetch_add(&lane_acc[0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -429,105 +433,129 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
                     __hip_atomic_fetch_add(&lane_acc[2], ps.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 ps.radiance = mk(0.f, 0.f, 0.f);
-                if (!cont) has_path = false;
-                else if (!(camera_phase | park)) trav_begin(sc, tv, ps.o, ps.d, stack_column(s_dyn, tv.top));
-                // else: the lane keeps its path without a ray; it goes to the queue right below
+                has_path = cont;
             }
-            if (camera_phase | park) {
-                // ---- queue the paths that go on: ballot + prefix compaction, three coalesced float4 stores
-                const bool push = has_path && !trav_active(tv);
-                const unsigned long long pmask = __ballot(push);
+            {
+                const unsigned long long pmask = __ballot(has_path);
                 if (pmask != 0ull) {
-                    if (push) {
-                        const uint32_t idx = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
+                    if (has_path) {
+                        const uint32_t idx = (tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u))) & qmask;
                         qa[idx] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
                         qb[idx] = make_float4(ps.d.y, ps.d.z, ps.throughput.x, ps.throughput.y);
                         qc[idx] = make_float4(ps.throughput.z, __uint_as_float(ps.rng), __uint_as_float((ps.bounce << 8) | pix), 0.f);
                         has_path = false;
                     }
-                    q_tail += (uint32_t)__popcll(pmask);
+                    tail += (uint32_t)__popcll(pmask);
                 }
             }
-            if (camera_phase) {
-                if (next < total && q_tail + 64u <= rp.pq_cap) {
-                    // ---- 64 camera rays: generate, one packet traversal; the loop's head shades them
-                    const uint32_t item = next + fresh_lane_id();
-                    next += 64u;
-                    bool valid = item < total;
-                    if (valid) {
-                        pix = __umulhi(item, rp.spp_magic);
-                        uint32_t sample = item - pix * rp.spp_count;
-                        if (sample >= rp.spp_count) { pix += 1u; sample -= rp.spp_count; }
-                        sample += rp.spp_begin;
-                        const int px = tile_x0 + (int)(pix & ((1u << rp.tile_w_log2) - 1u));
-                        const int py = tile_y0 + (int)(pix >> rp.tile_w_log2);
-                        valid = px < sc.width && py < sc.height;   // pixel outside the frame (partial edge tile): the item is dropped
-                        if (valid) generate(sc, ps, px, py, sample, rp.seed32);
-                    }
-                    trav_packet<N16>(sc, ps.o, ps.d, valid, tv.hit);
-                    has_path = valid;
-                    continue;   // tv.node == -1 in every lane here
+            const unsigned long long t_phase = STATS ? __builtin_readcyclecounter() : 0ull;
+            if (STATS) cnt.cyc[2] += t_phase - t_phase0;
+            // ---- shade phase: the next 64 traversed paths
+            if (shade_head != head) {
+                const uint32_t i = shade_head + fresh_lane_id();
+                const uint32_t left = head - shade_head;
+                if (i - shade_head < left) {
+                    const uint32_t idx = i & qmask;
+                    const float4 a = qa[idx], b = qb[idx], c = qc[idx], h = qh[idx];
+                    ps.o = mk(a.x, a.y, a.z);
+                    ps.d = mk(a.w, b.x, b.y);
+                    ps.throughput = mk(b.z, b.w, c.x);
+                    ps.rng = __float_as_uint(c.y);
+                    const uint32_t bp = __float_as_uint(c.z);
+                    ps.bounce = bp >> 8;
+                    pix = bp & 255u;
+                    hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.prim = __float_as_int(h.w);
+                    has_path = true;
                 }
-                camera_phase = false;
-                // the queue stores above are complete before the bounce phase loads them (same CU, same L1: workgroup scope)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            }
-            // ---- bounce phase refill: idle lanes take the next queue entries, in lane order
-            if (!park && q_head < q_tail) {
-                const bool want = !has_path;
-                const unsigned long long wmask = __ballot(want);
-                if (wmask != 0ull) {
-                    if (want) {
-                        const uint32_t idx = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
-                        if (idx < q_tail) {
-                            const float4 a = qa[idx], b = qb[idx], c = qc[idx];
-                            ps.o = mk(a.x, a.y, a.z);
-                            ps.d = mk(a.w, b.x, b.y);
-                            ps.throughput = mk(b.z, b.w, c.x);
-                            ps.rng = __float_as_uint(c.y);
-                            const uint32_t bp = __float_as_uint(c.z);
-                            ps.bounce = bp >> 8;
-                            pix = bp & 255u;
-                            trav_begin(sc, tv, ps.o, ps.d, stack_column(s_dyn, tv.top));
-                            has_path = true;
-                        }
-                    }
-                    q_head += (uint32_t)__popcll(wmask);
-                    if (q_head > q_tail) q_head = q_tail;
-                }
-            }
-            const uint32_t nP = (uint32_t)__popcll(__ballot(has_path));   // constant during the traversal phase
-            if (__ballot(trav_active(tv)) == 0ull) {
-                if (nP != 0u) continue;                 // paths whose ray ended at once (NaN direction): shade them
-                if (!park && q_head < q_tail) continue; // (every lane is idle here, so the refill above has emptied the queue)
-                if (next >= total) break;               // tile done
-                // back to the camera phase; parked paths stay at the head of the queue
-                if (!park) q_head = q_tail = 0u;
-                park = false;
-                camera_phase = true;
+                shade_head += left < 64u ? left : 64u;
                 continue;
             }
-            // Wind the bounce phase up? Only while camera paths are left: at the end of the tile the paths run to their end.
-            if (!park && q_head >= q_tail && next < total && nP <= rp.park_limit) {
-                park = true;
-                q_head = q_tail = 0u;
-            }
-            // ---- traverse until enough lanes are waiting again (k_megakernel's vote loop)
-            const uint32_t wait_limit = park ? nP : (nP < rp.refill_thresh ? nP : rp.refill_thresh);
-            __builtin_amdgcn_s_setprio(3);
-            for (;;) {
-                const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
-                const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
-                if (nP - (nI + nL) >= wait_limit) break;
-                if (nI * 4u >= nL * rp.sched_beta4) {
-#pragma unroll
-                    for (int r = 0; r < TRH_INNER_REPEAT; ++r)
-                        if (tv.node >= 0) trav_inner<false, N16>(sc, ps.o, tv, nullptr, cnt);
-                } else {
-                    if (tv.node < -1) trav_leaf<false>(sc, ps.o, ps.d, tv, nullptr, cnt);
+            // ---- camera phase: 64 camera rays, one packet traversal; the loop's head shades them
+            if (next < total && (tail - shade_head) + 64u <= rp.pq_cap && (tail - head) < rp.pq_target) {
+                const uint32_t item = next + fresh_lane_id();
+                next += 64u;
+                bool valid = item < total;
+                if (valid) {
+                    pix = __umulhi(item, rp.spp_magic);
+                    uint32_t sample = item - pix * rp.spp_count;
+                    if (sample >= rp.spp_count) { pix += 1u; sample -= rp.spp_count; }
+                    sample += rp.spp_begin;
+                    const int px = tile_x0 + (int)(pix & ((1u << rp.tile_w_log2) - 1u));
+                    const int py = tile_y0 + (int)(pix >> rp.tile_w_log2);
+                    valid = px < sc.width && py < sc.height;   // pixel outside the frame (partial edge tile): the item is dropped
+                    if (valid) generate(sc, ps, px, py, sample, rp.seed32);
                 }
+                trav_packet<N16>(sc, ps.o, ps.d, valid, hit);
+                has_path = valid;
+                if (STATS) { cnt.cyc[3] += __builtin_readcyclecounter() - t_phase; if (fresh_lane_id() == 0u) cnt.w_gen += 1; if (valid) cnt.l_gen += 1; }
+                continue;
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (head == tail) {
+                if (next >= total) break;   // nothing ready, nothing to shade, no items: tile done
+                continue;                   // (not reached: an empty ring always has room for the camera phase)
+            }
+            // ---- traverse phase: every ready ray, lanes refilled as they finish
+            // the ring stores above are complete before the loads below (same CU, same L1: workgroup scope)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            {
+                Trav tv;
+                tv.inv = tv.oi = mk(0.f, 0.f, 0.f);
+                tv.selx = tv.sely = tv.selz = 0x03020100u;
+                tv.node = -1;
+                tv.top = s_dyn + (wave_in_block * 64u + fresh_lane_id());
+                tv.hit.t = 0.f; tv.hit.u = tv.hit.v = 0.f; tv.hit.prim = -1; tv.hit.id = TRH_MISS_ID;
+                V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
+                uint32_t slot = 0;
+                bool has_ray = false;
+                __builtin_amdgcn_s_setprio(3);
+                for (;;) {
+                    // lanes that finished their ray store the hit beside the path and take the next ready ray
+                    const bool want = !trav_active(tv);
+                    if (want && has_ray) {
+                        qh[slot] = make_float4(tv.hit.t, tv.hit.u, tv.hit.v, __int_as_float(tv.hit.prim));
+                        has_ray = false;
+                    }
+                    if (head != tail) {
+                        const unsigned long long wmask = __ballot(want);
+                        if (want) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
+                            if (rank < tail - head) {
+                                slot = (head + rank) & qmask;
+                                const float4 a = qa[slot];
+                                const float2 b = *reinterpret_cast<const float2*>(&qb[slot]);
+                                ro = mk(a.x, a.y, a.z);
+                                rd = mk(a.w, b.x, b.y);
+                                trav_begin(sc, tv, ro, rd, stack_column(s_dyn, tv.top));
+                                has_ray = true;
+                            }
+                        }
+                        const uint32_t taken = (uint32_t)__popcll(wmask);
+                        head += taken < tail - head ? taken : tail - head;
+                    }
+                    const uint32_t nR = (uint32_t)__popcll(__ballot(has_ray));
+                    if (nR == 0u) break;   // ready rays used up (a lane without a ray found none), every hit stored
+                    // leave the vote loop when refill_thresh lanes have finished -- or all of them, once nothing is left to take
+                    const uint32_t wait_limit = (head != tail && rp.refill_thresh < nR) ? rp.refill_thresh : nR;
+                    for (;;) {
+                        const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
+                        const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
+                        if (nR - (nI + nL) >= wait_limit) break;
+                        const unsigned long long t_step = STATS ? __builtin_readcyclecounter() : 0ull;
+                        if (nI * 4u >= nL * rp.sched_beta4) {
+                            if (STATS && fresh_lane_id() == 0u) { cnt.idle_leaf += nL; cnt.idle_wait += nR - nI - nL; cnt.idle_none += 64u - nR; }
+#pragma unroll
+                            for (int r = 0; r < TRH_INNER_REPEAT; ++r)
+                                if (tv.node >= 0) trav_inner<STATS, N16>(sc, ro, tv, nullptr, cnt);
+                            if (STATS) cnt.cyc[0] += __builtin_readcyclecounter() - t_step;
+                        } else {
+                            if (tv.node < -1) trav_leaf<STATS>(sc, ro, rd, tv, nullptr, cnt);
+                            if (STATS) cnt.cyc[1] += __builtin_readcyclecounter() - t_step;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the hits are stored before the shade phase loads them
         }
         // ---- flush the tile: plain read-modify-write, the tile belongs to this wave
         __builtin_amdgcn_wave_barrier();
@@ -553,7 +581,8 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
             rp.tile_cost[tile] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
         }
     }
-    flush_counters<false>(cnt, counters);
+    if (STATS) cnt.cyc[4] += __builtin_readcyclecounter() - t_kernel;
+    flush_counters<STATS>(cnt, counters);
 }
 
 template <bool N16>
@@ -640,10 +669,10 @@ __global__ void k_present(const float4* __restrict__ accum, uint32_t* __restrict
 
 // ---- scratch of trh_render_noalloc (include/tracy_hip.h): the tile counter and the tile-order arrays of ONE launch
 // sequence, in a file-scope device array instead of hipMalloc'ed memory. Every GPU the library runs on holds its own
-// copy (6.25 MiB) at its own address until the process ends; host code never uses the array's name as an address but
+// copy (9.25 MiB) at its own address until the process ends; host code never uses the array's name as an address but
 // the per-device pointer trh_init obtains with hipGetSymbolAddress (g_scratch_ptr).
 constexpr uint32_t kNoAllocMaxTiles = 1u << 18;                  // 262 144 tiles: 1080p and 4K at >= 8 spp per launch fit
-constexpr size_t kNoAllocSortTempBytes = 1u << 20;               // hipcub radix-sort temporary storage for that many keys
+constexpr size_t kNoAllocSortTempBytes = 4u << 20;               // hipcub radix-sort temporary storage for that many keys (separate in/out arrays: a second key and value array + histograms)
 constexpr size_t kNoAllocArrayBytes = (size_t)kNoAllocMaxTiles * sizeof(uint32_t);
 constexpr size_t kNoAllocScratchBytes = 256 + 5 * kNoAllocArrayBytes + kNoAllocSortTempBytes;
 static __device__ __align__(256) unsigned char g_scratch[kNoAllocScratchBytes];
@@ -723,11 +752,13 @@ struct trh_context {
     uint32_t sched_beta4 = 6;
     size_t lds_pad = 0;
     // k_megakernel_ab: the bounce queues of the resident waves (allocated at the first launch, freed with the scene)
+    bool stats_ab = false;         // TRH_STATS_AB=1 (development): the instrumented launch runs k_megakernel_ab too (phase times, lane utilisation)
     bool camera_packets = true;    // TRH_CAMERA_PACKETS=0: the round-2 kernel (k_megakernel) for every launch
     float4* pq = nullptr;
     size_t pq_waves = 0;           // wave slots the allocation holds
-    uint32_t pq_cap = 4096;        // entries per wave
-    uint32_t park_limit = 40;
+    uint32_t pq_cap = 512;         // ring entries per wave (a power of two): 32 KB per wave; swept 256..4096, profiles/r03_ring_sweeps.txt
+    uint32_t pq_target = 448;      // ready rays that end the camera phase
+    uint32_t ab_refill_thresh = 16;   // finished lanes that end a vote loop of the traverse phase (their refill is a 32-byte load)
     // device buffer of the parity probes (trh_primary_hits / trh_sample_radiance), grown on demand, freed at shutdown
     void* probe_buf = nullptr;
     size_t probe_bytes = 0;
@@ -894,9 +925,9 @@ int launch_megakernel_tiled(trh_context* c, TileState& ts, RenderParams rp, uint
     // Camera rays as packets + bounce queue (k_megakernel_ab) for every launch of the context's own tile state; the
     // instrumented kernel counts the per-ray work of the lane scheduler (the algorithmic figure of the roofline), and
     // trh_render_noalloc (a tile state in the static scratch) has no queue memory: both run k_megakernel.
-    const bool ab = !STATS && c->camera_packets && &ts == &c->ts;
+    const bool ab = (!STATS || c->stats_ab) && c->camera_packets && c->pipeline == TRH_PIPELINE_MEGAKERNEL && &ts == &c->ts;
     int per_cu = 0;
-    if (ab) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel_ab<N16>, TRH_BLOCK, lds));
+    if (ab) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel_ab<STATS, N16>, TRH_BLOCK, lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel<STATS, N16>, TRH_BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     const int grid = per_cu * c->num_cus;
@@ -911,17 +942,18 @@ int launch_megakernel_tiled(trh_context* c, TileState& ts, RenderParams rp, uint
                 c->pq_waves = 0;
             }
             void* p = nullptr;
-            HIP_TRY(hipMalloc(&p, waves * 3u * c->pq_cap * sizeof(float4)));
+            HIP_TRY(hipMalloc(&p, waves * 4u * c->pq_cap * sizeof(float4)));
             c->allocs.push_back(p);
             c->pq = (float4*)p;
             c->pq_waves = waves;
         }
         rp.pq = c->pq;
         rp.pq_cap = c->pq_cap;
-        rp.park_limit = c->park_limit;
+        rp.pq_target = std::min(c->pq_target, c->pq_cap - 64u);
+        rp.refill_thresh = c->ab_refill_thresh;
     }
     HIP_TRY(hipMemsetAsync(ts.tile_counter, 0, sizeof(unsigned int), c->stream));
-    if (ab) hipLaunchKernelGGL((k_megakernel_ab<N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, ts.tile_counter);
+    if (ab) hipLaunchKernelGGL((k_megakernel_ab<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, ts.tile_counter);
     else hipLaunchKernelGGL((k_megakernel<STATS, N16>), dim3(grid), dim3(TRH_BLOCK), lds, c->stream, c->sc, rp, c->accum, c->counters, ts.tile_counter);
     HIP_TRY(hipGetLastError());
     if (ordered) {
@@ -1202,17 +1234,20 @@ int trh_init(int device, trh_context** ctx_out) {
         if (v >= 8 && v <= 26) c->wf_pool_limit = 1u << v;
     }
     if (const char* e = getenv("TRH_LDS_PAD")) c->lds_pad = (size_t)atoi(e);
+    if (const char* e = getenv("TRH_STATS_AB")) c->stats_ab = atoi(e) != 0;
     if (const char* e = getenv("TRH_CAMERA_PACKETS")) c->camera_packets = atoi(e) != 0;   // development knob: 0 = k_megakernel for every launch
-    if (const char* e = getenv("TRH_PQ_CAP")) {             // development knob: bounce-queue entries per wave
+    if (const char* e = getenv("TRH_PQ_CAP")) {             // development knob: ring entries per wave (rounded up to a power of two)
         const int v = atoi(e);
-        if (v >= 128 && v <= (1 << 20)) c->pq_cap = ((uint32_t)v + 63u) & ~63u;
+        if (v >= 128 && v <= (1 << 20)) { uint32_t p2 = 128; while (p2 < (uint32_t)v) p2 <<= 1; c->pq_cap = p2; }
     }
-    if (const char* e = getenv("TRH_PARK_LIMIT")) {         // development knob
+    if (const char* e = getenv("TRH_PQ_TARGET")) {          // development knob
         const int v = atoi(e);
-        if (v >= 0 && v <= 64) c->park_limit = (uint32_t)v;
+        if (v >= 1) c->pq_target = (uint32_t)v;
     }
-    if (const char* e = getenv("TRH_TILE_FEEDBACK")) c->tile_feedback = atoi(e) != 0;   // development knob: 0 = raster order always
-    if (const char* e = getenv("TRH_BUILDER")) c->builder = strcmp(e, "lbvh") == 0 ? TRH_BUILDER_DEVICE_LBVH : TRH_BUILDER_HOST_SAH;   // default builder of this context
+    if (const char* e = getenv("TRH_AB_REFILL")) {          // development knob
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) c->ab_refill_thresh = (uint32_t)v;
+    }
     if (const char* e = getenv("TRH_SCHED_BETA4")) {     // development knob
         const int v = atoi(e);
         if (v >= 1 && v <= 256) c->sched_beta4 = (uint32_t)v;   // >= 1: the vote relies on it (0 was round 1's while-while mode)
@@ -1571,7 +1606,8 @@ int trh_set_debug_view(trh_context* c, int view, const float view3x3[9]) {
 
 int trh_set_pipeline(trh_context* c, int pipeline) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: ctx is NULL");
-    if (pipeline != TRH_PIPELINE_MEGAKERNEL && pipeline != TRH_PIPELINE_MEGAKERNEL_SIMPLE && pipeline != TRH_PIPELINE_WAVEFRONT)
+    if (pipeline != TRH_PIPELINE_MEGAKERNEL && pipeline != TRH_PIPELINE_MEGAKERNEL_SIMPLE && pipeline != TRH_PIPELINE_WAVEFRONT &&
+        pipeline != TRH_PIPELINE_MEGAKERNEL_LANES)
         return fail(TRH_ERR_INVALID_ARG, "trh_set_pipeline: unknown pipeline");
     c->pipeline = pipeline;
     return TRH_OK;
@@ -1588,7 +1624,8 @@ int trh_render_stats(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uin
 int trh_render_noalloc(trh_context* c, uint32_t spp_begin, uint32_t spp_count, uint64_t seed) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_render_noalloc: ctx is NULL");
     if (!c->has_scene || !c->has_camera) return fail(TRH_ERR_STATE, "trh_render_noalloc: scene and camera must be uploaded first");
-    if (c->pipeline != TRH_PIPELINE_MEGAKERNEL) return fail(TRH_ERR_STATE, "trh_render_noalloc: only the megakernel pipeline runs without allocations");
+    if (c->pipeline != TRH_PIPELINE_MEGAKERNEL && c->pipeline != TRH_PIPELINE_MEGAKERNEL_LANES)
+        return fail(TRH_ERR_STATE, "trh_render_noalloc: only the megakernel pipeline runs without allocations");
     if (spp_count == 0) return TRH_OK;
     if (spp_count > (1u << 16)) return fail(TRH_ERR_LIMIT, "trh_render_noalloc: more than 65536 samples per pixel in one call");
     if ((uint64_t)spp_begin + spp_count > 0xffffffffull) return fail(TRH_ERR_LIMIT, "trh_render_noalloc: sample index exceeds 32 bits");
@@ -1630,6 +1667,9 @@ int trh_render_noalloc(trh_context* c, uint32_t spp_begin, uint32_t spp_count, u
     c->accum_spp += spp_count;
     return TRH_OK;
 }
+
+// development / test aid (not declared in the header): temporary storage the tile sort asks for at `ntiles` tiles
+size_t trh_debug_sort_temp_bytes(uint32_t ntiles) { return tile_order::scratch_bytes(ntiles); }
 
 int trh_synchronize(trh_context* c) {
     if (!c) return fail(TRH_ERR_INVALID_ARG, "trh_synchronize: ctx is NULL");
