@@ -363,7 +363,8 @@ DEVFN void trav_packet(const DevScene& sc, V3 o, V3 d, bool valid, Hit& hit) {
     const bool act = valid && !(d.x != d.x);   // NaN direction: a miss (trav_begin)
     uint32_t vstack = 0;                        // lane i = stack entry i
     uint32_t sp = 0;
-    int node = __ballot(act) != 0ull ? 0 : -1;
+    const unsigned long long actm = __builtin_amdgcn_ballot_w64(act);   // wave-uniform mask of the lanes that hold a ray
+    int node = actm != 0ull ? 0 : -1;
     for (;;) {
         if (node >= 0) {
             float tmin0, tmax0, tmin1, tmax1;
@@ -398,11 +399,11 @@ DEVFN void trav_packet(const DevScene& sc, V3 o, V3 d, bool valid, Hit& hit) {
                 tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), hit.t));
                 c0 = (int)q[12]; c1 = (int)q[13];
             }
-            const bool h0 = act & (tmin0 <= tmax0);
-            const bool h1 = act & (tmin1 <= tmax1);
-            const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+            // (masks, not per-lane booleans: __ballot(int) would materialise 0 / 1 in a VGPR and compare it again)
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(tmin0 <= tmax0) & actm;
+            const unsigned long long b1 = __builtin_amdgcn_ballot_w64(tmin1 <= tmax1) & actm;
             if ((b0 != 0ull) & (b1 != 0ull)) {
-                const unsigned long long sw = __ballot(h1 & (!h0 | (tmin1 < tmin0)));   // lanes for which child 1 is the nearer (or only) hit
+                const unsigned long long sw = b1 & (~b0 | __builtin_amdgcn_ballot_w64(tmin1 < tmin0));   // lanes for which child 1 is the nearer (or only) hit
                 const bool first1 = 2u * (uint32_t)__popcll(sw) > (uint32_t)__popcll(b0 | b1);
                 vstack = write_lane(vstack, sp, (uint32_t)(first1 ? c0 : c1));
                 sp += 1u;

@@ -758,7 +758,7 @@ struct trh_context {
     size_t pq_waves = 0;           // wave slots the allocation holds
     uint32_t pq_cap = 512;         // ring entries per wave (a power of two): 32 KB per wave; swept 256..4096, profiles/r03_ring_sweeps.txt
     uint32_t pq_target = 448;      // ready rays that end the camera phase
-    uint32_t ab_refill_thresh = 16;   // finished lanes that end a vote loop of the traverse phase (their refill is a 32-byte load)
+    uint32_t ab_refill_thresh = 24;   // finished lanes that end a vote loop of the traverse phase (their refill is a 32-byte load)
     // device buffer of the parity probes (trh_primary_hits / trh_sample_radiance), grown on demand, freed at shutdown
     void* probe_buf = nullptr;
     size_t probe_bytes = 0;
