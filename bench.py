@@ -4,7 +4,9 @@
 
     python bench.py --gpus 1 --steps 8 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # one process per GPU, torch.distributed over RCCL
+    python bench.py --gpus N --steps K --warmup W                   # ONE process, one host thread, N devices behind the C ABI
+                                                                     # (trh_group_*: the shape Tracy's main() needs)
 
 Default workload = BASELINE.json configs[3] as it is written: 4096 samples per pixel in all, sample-
 partitioned over the N GPUs -- rank g owns the global sample indices [g*4096/N, (g+1)*4096/N)
@@ -29,6 +31,27 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+RENDER_KERNEL = "k_megakernel_ab<false, true>"   # rocprofv3's name of the dominant kernel (default pipeline, fp16 node records)
+
+
+def pmc_traffic(scene, W, H, spp):
+    """HBM-side bytes of ONE launch of `spp` samples per pixel from the PMC counters (profiles/pmc_traffic.json, written by
+    tools/profile_bench.sh from separate --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE as the MICROARCH guide prescribes). An
+    exact entry for this launch size if the profile has one, else the profile's linear model bytes = fixed + per_spp * spp
+    (measured at two or more launch sizes of this workload), else None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    key = f"{scene}_{W}x{H}"
+    if f"{key}_{spp}spp" in t:
+        return t[f"{key}_{spp}spp"]
+    m = t.get(f"{key}_model")
+    if m:
+        return m["fixed_bytes"] + m["bytes_per_spp"] * spp
+    return None
+
 
 
 def algorithmic_flops(st):
@@ -89,6 +112,94 @@ def psnr_vs_oracle(mod, scene, spp):
     return 200.0 if mse == 0.0 else 10.0 * np.log10(1.0 / mse)
 
 
+def main_group(args):
+    """--gpus N without a launcher: ONE process, one host thread, N devices behind the C ABI (trh_group_*,
+    csrc/hip/tracy_group.hip) -- the shape the reference's single-threaded main() needs (src/win_raytracer.cpp:480,494-517).
+    Every timed step is one trh_group_render of total_spp / K samples, split over the devices by sample index
+    ([g*S/G, (g+1)*S/G) of the step's S samples: N launches in flight from this thread); the timed region ends with
+    trh_group_resolve: the one ncclReduce(sum, f32, W*H*4, root 0) inside ncclGroupStart/End + the mean on device 0."""
+    import ctypes as C
+    from tracy_amd import Scene, HipTrace, HipTraceGroup, capi
+    n = C.c_int(0)
+    capi.hip_lib().trh_device_count(C.byref(n))
+    rehearsal = n.value < args.gpus
+    if rehearsal:
+        if not args.alias_devices:
+            raise SystemExit(f"--gpus {args.gpus} but this box has {n.value} HIP device(s); --alias-devices rehearses the N>1 control flow on shared devices")
+        os.environ["TRH_GROUP_ALIAS_DEVICE"] = "1"
+    scene = Scene(f"data/scenes/{args.scene}.scn", args.width, args.height)
+    W, H = scene.width, scene.height
+    if args.total_spp < args.steps * args.gpus:
+        raise SystemExit(f"--total-spp {args.total_spp} over {args.gpus} devices and {args.steps} steps leaves launches without samples")
+    S = -(-args.total_spp // args.steps)                    # samples per step over all devices (ceil)
+    S_dev = -(-S // args.gpus)                              # ... and per device launch
+
+    def step_range(k):
+        if k < args.warmup:
+            return args.total_spp + k * S, S
+        j = k - args.warmup
+        lo, hi = (j * args.total_spp) // args.steps, ((j + 1) * args.total_spp) // args.steps
+        return lo, hi - lo
+
+    # ---- instrumented pass (untimed, one device): the roofline numerator for one device launch of this workload
+    one = HipTrace(device=0)
+    one.Startup(scene)
+    one.stats(reset=True)
+    one.render(0, S_dev, stats=True)
+    st_algo = one.stats(reset=True)
+    bvh = one.bvh_info()
+    one.Shutdown()
+
+    grp = HipTraceGroup(ngpus=args.gpus)
+    grp.Startup(scene)
+    if grp.ngpus != args.gpus:
+        raise SystemExit(f"the group has {grp.ngpus} members, not {args.gpus}")
+    step = 0
+    for _ in range(args.warmup):
+        grp.render(*step_range(step))
+        step += 1
+    grp.resolve(to_host=False)         # warms the exchange step up too (communicator, reduced buffer)
+    grp.reset()
+    grp.synchronize()
+    grp.stats(reset=True)
+    first_timed = step_range(step)[0]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        grp.render(*step_range(step))
+        step += 1
+    grp.resolve(to_host=False)         # exchange step + mean on device 0; returns when every device's stream has drained
+    dt = time.perf_counter() - t0
+    st = grp.stats(reset=False)
+    t1 = time.perf_counter()
+    img, spp_done = grp.resolve(to_host=True)
+    d2h_ms = (time.perf_counter() - t1) * 1e3
+    if args.save:
+        np.save(args.save, img)
+    kernel_ms = st["kernel_ms"] / max(1, st["launches"])    # slowest device: mean over its launches
+    launch_scale = (args.total_spp / args.steps / args.gpus) / S_dev
+    flops_launch = algorithmic_flops(st_algo) * launch_scale
+    achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
+    out = {
+        "metric": "Msamples/s @1080p dragon scene (path tracing, <=5 bounces, Russian roulette)",
+        "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "mrays_per_s": st["rays"] / dt / 1e6,
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"{args.scene}.scn {W}x{H}, {scene.tri_count} triangles, max 5 bounces + Russian roulette, seed 0xABCDEF "
+                                f"(BASELINE.json configs[3]); {args.total_spp} spp in all, {args.steps} steps of {args.total_spp // args.steps}-{S} spp, "
+                                f"every step sample-partitioned over {args.gpus} device(s) ([g*S/G,(g+1)*S/G))"),
+                   "spp_per_step": S, "spp_per_device_launch": S_dev, "total_spp": int(spp_done), "first_sample_index": first_timed,
+                   "parallelism": (f"ONE process, one host thread: trh_group_* over {args.gpus} devices, one ncclReduce(sum) to device 0 per resolve"
+                                   + (" (ALIAS REHEARSAL on fewer devices: members share GPUs, device-side sum -- not a measurement)" if rehearsal else "")),
+                   "pipeline": "megakernel", "bvh": bvh, "rays_per_sample": st["rays"] / max(1, st["samples"])},
+        "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                     "traffic": pmc_traffic(args.scene, W, H, S_dev), "kernel": RENDER_KERNEL, "kernel_ms_avg": kernel_ms,
+                     "spp_per_launch": S_dev, "flops_per_launch": flops_launch, "note": "per device (slowest member)"},
+        "d2h_resolve_ms": d2h_ms,
+    }
+    print(json.dumps(out), flush=True)
+    grp.Shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +214,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save", default=None, help="rank 0: write the resolved image as .npy")
+    ap.add_argument("--alias-devices", action="store_true",
+                    help="single-process form on a box with fewer GPUs than --gpus: the group's members share devices "
+                         "(TRH_GROUP_ALIAS_DEVICE=1, device-side sum instead of RCCL). A REHEARSAL of the N>1 control flow, not a measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the product path). gloo = rehearsal of the N>1 control flow on a box with fewer GPUs "
                          "than ranks: ranks share devices and the exchange step is staged through host memory")
@@ -114,10 +228,13 @@ def main():
     from tracy_amd import sharding
 
     rank, world, local_rank = sharding.env_rank_world()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if world == 1 and args.gpus > 1:
+        return main_group(args)      # no launcher: this one process drives the N devices itself (trh_group_*)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or without a launcher (one process drives the devices through trh_group_*)")
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -224,13 +341,7 @@ def main():
         bvh = mod.bvh_info()
         bytes_launch = algorithmic_bytes(st_algo, bvh["node_bytes"] / max(1, bvh["node_count"])) * launch_scale
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(f"{args.scene}_{W}x{H}_{S}spp")   # PMC bytes of one launch of this size, or None
-            except Exception:
-                traffic = None
+        traffic = pmc_traffic(args.scene, W, H, S)
         out = {
             "metric": "Msamples/s @1080p dragon scene (path tracing, <=5 bounces, Russian roulette)",
             "value": total_samples / dt / 1e6,
@@ -247,11 +358,11 @@ def main():
                                      f"each share traced in {args.steps} steps of {my_count // args.steps}-{S} spp")),
                        "spp_per_step": S, "total_spp": int(round(total_samples / (W * H))), "first_sample_index": first_timed,
                        "parallelism": f"sample-index sharding x{world}, one sum-reduce to rank 0" + ("" if args.backend == "nccl" else " (gloo REHEARSAL, not a measurement)"),
-                       "pipeline": "megakernel" if not args.pipeline else "wavefront",
+                       "pipeline": {0: "megakernel (camera / traverse / shade phases per wave)", 1: "wavefront", 2: "megakernel_simple", 3: "megakernel_lanes (round 2)"}[args.pipeline or 0],
                        "bvh": bvh, "rays_per_sample": total_rays / total_samples},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "k_megakernel<false, true>" if not args.pipeline else "wavefront", "kernel_ms_avg": kernel_ms,
+                         "kernel": RENDER_KERNEL if not args.pipeline else f"pipeline {args.pipeline}", "kernel_ms_avg": kernel_ms,
                          "spp_per_launch": S,
                          "flops_per_launch": flops_launch,
                          "per_ray": {"box_tests": st_algo["box_tests"] / st_algo["rays"], "tri_tests": st_algo["tri_tests"] / st_algo["rays"],

@@ -146,3 +146,87 @@ def test_two_device_group_equals_one_device(gpu_available):
     assert rays == rays_ref                      # the same sample set, whatever the device count
     np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)   # float summation order only
     assert _differing(np.ascontiguousarray(img[..., 3]), np.ascontiguousarray(ref[..., 3])) == 0
+
+
+# ---- the N > 1 path on a one-GPU box: TRH_GROUP_ALIAS_DEVICE=1 lets the members of a group share device 0 (own context,
+# stream, scene replica and accumulation buffer each); the exchange step is a device-side sum where RCCL would refuse
+# duplicate devices. Everything else is the code a real N-GPU group runs (tracy_group.hip).
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("members", [2, 3])
+def test_alias_group_equals_one_context(gpu_available, monkeypatch, members):
+    assert gpu_available, "needs a HIP device"
+    import ctypes as C
+    from tracy_amd import capi, HipTrace, HipTraceGroup
+    sc = load_scene("dragon", 480, 270)
+    one = HipTrace(device=0)
+    one.Startup(sc)
+    one.render(0, 32)
+    ref32, _ = one.resolve()
+    one.render(32, 32)
+    ref, _ = one.resolve()
+    pic_ref = one.present()
+    rays_ref = one.stats()["rays"]
+    bvh_ref = one.bvh_info()
+    one.Shutdown()
+
+    monkeypatch.setenv("TRH_GROUP_ALIAS_DEVICE", "1")
+    grp = HipTraceGroup(ngpus=members)
+    grp.Startup(sc)
+    assert grp.ngpus == members
+    # the host-built BVH is built once and uploaded to every member
+    lib = capi.hip_lib()
+    for i in range(members):
+        ctx = C.c_void_p()
+        assert lib.trh_group_context(grp._grp, i, C.byref(ctx)) == 0
+        b = capi.trh_bvh_info()
+        assert lib.trh_get_bvh_info(ctx, C.byref(b)) == 0
+        assert (b.node_count, b.tri_count, b.max_depth) == (bvh_ref["node_count"], bvh_ref["tri_count"], bvh_ref["max_depth"])
+    grp.render(0, 32)
+    mid, n_mid = grp.resolve()       # a resolve in the middle leaves the per-member sums intact
+    mid2, _ = grp.resolve()
+    grp.render(32, 32)
+    img, ns = grp.resolve()
+    pic = grp.present()
+    rays = grp.stats()["rays"]
+    grp.Shutdown()
+    assert n_mid == 32 and ns == 64
+    assert rays == rays_ref                      # the same sample set, whatever the member count
+    assert _differing(mid, mid2) == 0
+    for got, want in ((mid, ref32), (img, ref)):
+        np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=2e-6, atol=1e-7)   # float summation order only
+        assert _differing(np.ascontiguousarray(got[..., 3]), np.ascontiguousarray(want[..., 3])) == 0
+    assert (pic != pic_ref).mean() < 1e-3        # 8-bit picture: a rounding flip here and there at most
+
+
+@pytest.mark.gpu
+def test_alias_group_render_failure_leaves_a_consistent_state(gpu_available, monkeypatch):
+    """A member that fails its launch after earlier members were enqueued (injected: TRH_GROUP_FAIL_MEMBER) must not
+    leave accum_spp out of step with the buffers unnoticed: the group refuses render / resolve / present until
+    trh_group_reset_accumulation, and is then as good as new. A failure of member 0 (nothing launched yet) changes nothing."""
+    assert gpu_available, "needs a HIP device"
+    from tracy_amd import HipError, HipTraceGroup
+    sc = load_scene("cornell", 320, 180)
+    monkeypatch.setenv("TRH_GROUP_ALIAS_DEVICE", "1")
+    grp = HipTraceGroup(ngpus=3)
+    grp.Startup(sc)
+    grp.render(0, 12)
+    good, n = grp.resolve()
+    assert n == 12
+    monkeypatch.setenv("TRH_GROUP_FAIL_MEMBER", "0")
+    with pytest.raises(HipError, match="injected"):
+        grp.render(12, 12)
+    same, n = grp.resolve()                      # nothing was launched: state unchanged
+    assert n == 12 and _differing(same, good) == 0
+    monkeypatch.setenv("TRH_GROUP_FAIL_MEMBER", "2")
+    with pytest.raises(HipError, match="injected"):
+        grp.render(12, 12)
+    monkeypatch.delenv("TRH_GROUP_FAIL_MEMBER")
+    for call in (lambda: grp.render(24, 3), grp.resolve, grp.present):
+        with pytest.raises(HipError, match="part-way"):
+            call()
+    grp.reset()
+    grp.render(0, 12)
+    again, n = grp.resolve()
+    grp.Shutdown()
+    assert n == 12 and _differing(again, good) == 0

@@ -15,6 +15,7 @@ int fail(int code, const std::string& msg);   // sets trh_last_error(), returns 
 int device_of(const trh_context* c);
 hipStream_t stream_of(const trh_context* c);
 int builder_of(const trh_context* c);
+bool can_render(const trh_context* c);   // scene and camera are set: trh_render will not refuse for lack of either
 // device pointer of the context's accumulation buffer (rgb sums + count) and its element count (floats)
 float* accum_of(const trh_context* c, size_t* float_count);
 

@@ -8,6 +8,13 @@
 // without any host synchronisation), then mean / tonemap on device 0. Nothing else crosses devices: paths are
 // independent, the accumulation is a commutative sum.
 //
+// TRH_GROUP_ALIAS_DEVICE=1 (a test knob for boxes with fewer GPUs than members): the members of a group may share
+// devices -- member i runs on device i mod (devices present), every member with its own context, stream, scene replica
+// and accumulation buffer -- and the exchange step is a device-side sum (k_group_add on the root's stream, ordered after
+// the members' streams by events) where RCCL would refuse a communicator with duplicate devices. Everything else of
+// the N > 1 path (shared host-built BVH uploaded N times, the sample split, N launches in flight from one thread, the
+// separate `reduced` buffer, resolve / present from it) is the code a real N-GPU group runs.
+//
 // RCCL is bound at run time (dlopen of librccl.so.1) the first time a group of more than one device is made: hosts
 // with one GPU never load it, and a process that already holds a copy (PyTorch ships one) shares that copy instead
 // of mapping a second one.
@@ -83,10 +90,25 @@ bool load_rccl() {
 
 }  // namespace
 
+// reduced += member (float frames on one device): the alias-device form of the exchange step
+__global__ void k_group_add(float4* __restrict__ reduced, const float4* __restrict__ member, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = reduced[i];
+    const float4 b = member[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    reduced[i] = a;
+}
+
 struct trh_group {
     std::vector<trh_context*> ctx;     // ctx[g] renders on device g; ctx[0] is the root (reduce target, resolve, present)
     std::vector<ncclComm_t> comms;     // one communicator per device, made by ncclCommInitAll; empty without RCCL
     bool use_rccl = false;
+    bool alias = false;                // TRH_GROUP_ALIAS_DEVICE: members share devices, the exchange step is k_group_add
+    bool exchange = false;             // the group has an exchange step (RCCL or alias): resolve / present read `reduced`
+    bool torn = false;                 // a render call failed after some members had been launched: the sums are not those of
+                                       // accum_spp samples any more; every call but reset / upload / shutdown refuses
+    std::vector<hipEvent_t> done;      // alias: one event per member, recorded on its stream before the sum
     float* reduced = nullptr;          // device 0: W*H float4, the sum over devices (the per-device sums stay untouched)
     size_t reduced_floats = 0;
     bool has_scene = false;
@@ -110,6 +132,8 @@ int trh_group_shutdown(trh_group* g) {
     if (g->use_rccl)
         for (ncclComm_t c : g->comms)
             if (c) (void)g_rccl.CommDestroy(c);
+    for (hipEvent_t e : g->done)
+        if (e) (void)hipEventDestroy(e);
     if (g->reduced && !g->ctx.empty() && g->ctx[0]) {
         (void)hipSetDevice(trh_internal::device_of(g->ctx[0]));
         (void)hipFree(g->reduced);
@@ -126,11 +150,15 @@ int trh_group_init(int ngpus_requested, int* ngpus_out, trh_group** group_out) {
     int have = 0;
     if (int rc = trh_device_count(&have)) return rc;
     if (have == 0) return fail(TRH_ERR_NO_DEVICE, "trh_group_init: no HIP device (this module has no CPU fallback)");
-    const int n = ngpus_requested <= 0 ? have : std::min(ngpus_requested, have);   // <= 0: every device of the node
+    const char* alias_env = getenv("TRH_GROUP_ALIAS_DEVICE");
+    const bool alias = alias_env && atoi(alias_env) != 0 && ngpus_requested > have;
+    if (alias && ngpus_requested > 64) return fail(TRH_ERR_LIMIT, "trh_group_init: more than 64 members");
+    const int n = alias ? ngpus_requested : (ngpus_requested <= 0 ? have : std::min(ngpus_requested, have));   // <= 0: every device of the node
     auto* g = new trh_group();
+    g->alias = alias;
     g->ctx.assign((size_t)n, nullptr);
     for (int i = 0; i < n; ++i) {
-        if (int rc = trh_init(i, &g->ctx[(size_t)i])) {
+        if (int rc = trh_init(alias ? 0 : i, &g->ctx[(size_t)i])) {
             const std::string why = trh_last_error();
             trh_group_shutdown(g);
             return fail(rc, why);
@@ -139,7 +167,16 @@ int trh_group_init(int ngpus_requested, int* ngpus_out, trh_group** group_out) {
     // one device needs no exchange step; TRH_GROUP_FORCE_RCCL=1 runs it all the same (a 1-rank reduce is a copy), so
     // that the RCCL path can be exercised on a one-GPU box
     const char* force = getenv("TRH_GROUP_FORCE_RCCL");
-    g->use_rccl = n > 1 || (force && atoi(force) != 0);
+    g->use_rccl = !alias && (n > 1 || (force && atoi(force) != 0));
+    g->exchange = g->use_rccl || alias;
+    if (alias) {
+        g->done.assign((size_t)n, nullptr);
+        for (int i = 0; i < n; ++i)
+            if (hipEventCreateWithFlags(&g->done[(size_t)i], hipEventDisableTiming) != hipSuccess) {
+                trh_group_shutdown(g);
+                return fail(TRH_ERR_HIP, "trh_group_init: hipEventCreate failed");
+            }
+    }
     if (g->use_rccl) {
         if (!load_rccl()) {
             const std::string why = "trh_group_init: cannot load RCCL (" + g_rccl.error + ")";
@@ -174,7 +211,10 @@ int trh_group_context(trh_group* g, int index, trh_context** ctx_out) {
 
 int trh_group_scene_upload(trh_group* g, const trh_scene_desc* scene) {
     if (!g || !scene) return fail(TRH_ERR_INVALID_ARG, "trh_group_scene_upload: NULL argument");
+    // a failure below leaves the members with different scenes: has_scene stays false and every render / resolve call
+    // refuses until an upload has gone through on all of them
     g->has_scene = false;
+    g->torn = false;
     // the host builder runs ONCE; every device gets its own replica of the arrays (dragon: 15 MB). The device-side
     // builder runs on every device (milliseconds, and the arrays are born in that device's HBM).
     bvh::Result shared;
@@ -188,7 +228,7 @@ int trh_group_scene_upload(trh_group* g, const trh_scene_desc* scene) {
         }
         if (int rc = trh_internal::scene_upload_shared(g->ctx[i], scene, have_shared ? &shared : nullptr, from_cache, build_ms)) return rc;
     }
-    if (g->use_rccl) {
+    if (g->exchange) {
         size_t floats = 0;
         (void)trh_internal::accum_of(g->ctx[0], &floats);
         HIP_TRY(hipSetDevice(trh_internal::device_of(g->ctx[0])));
@@ -234,20 +274,35 @@ int trh_group_reset_accumulation(trh_group* g) {
     for (trh_context* c : g->ctx)
         if (int rc = trh_reset_accumulation(c)) return rc;
     g->accum_spp = 0;
+    g->torn = false;
     return TRH_OK;
 }
 
 int trh_group_render(trh_group* g, uint32_t spp_begin, uint32_t spp_count, uint64_t seed) {
     if (!g) return fail(TRH_ERR_INVALID_ARG, "trh_group_render: group is NULL");
     if (!g->has_scene) return fail(TRH_ERR_STATE, "trh_group_render: no scene");
+    if (g->torn) return fail(TRH_ERR_STATE, "trh_group_render: an earlier render call failed part-way; call trh_group_reset_accumulation first");
     if ((uint64_t)spp_begin + spp_count > 0xffffffffull) return fail(TRH_ERR_LIMIT, "trh_group_render: sample index exceeds 32 bits");
     const int n = (int)g->ctx.size();
+    // everything trh_render can refuse is checked for ALL members before the first launch, so that a refusal leaves
+    // the per-member sums and accum_spp in step
+    for (int i = 0; i < n; ++i)
+        if (!trh_internal::can_render(g->ctx[(size_t)i])) return fail(TRH_ERR_STATE, "trh_group_render: scene and camera must be set on every member first");
     // asynchronous on every device's stream: the host thread only enqueues, the N launches run side by side
+    int launched = 0;
     for (int i = 0; i < n; ++i) {
         uint32_t b = 0, cnt = 0;
         trh_split_samples(spp_begin, spp_count, n, i, &b, &cnt);
         if (cnt == 0) continue;
-        if (int rc = trh_render(g->ctx[(size_t)i], b, cnt, seed)) return rc;
+        const char* inject = getenv("TRH_GROUP_FAIL_MEMBER");   // test knob: member k fails its launch (tests/test_group.py)
+        int rc = (inject && *inject && atoi(inject) == i) ? fail(TRH_ERR_HIP, "trh_group_render: injected failure (TRH_GROUP_FAIL_MEMBER)")
+                                                           : trh_render(g->ctx[(size_t)i], b, cnt, seed);
+        if (rc) {
+            // a device error after earlier members were launched: their buffers hold samples accum_spp does not count
+            if (launched > 0) g->torn = true;
+            return rc;
+        }
+        ++launched;
     }
     g->accum_spp += spp_count;
     return TRH_OK;
@@ -264,8 +319,37 @@ int trh_group_synchronize(trh_group* g) {
 
 namespace {
 
+// the alias-device exchange step: reduced = member 0, then += every other member, on the root's stream after each
+// member's stream has reached this point (same order of additions as a chain reduce over ranks 0, 1, 2, ...)
+int sum_to_root_alias(trh_group* g) {
+    const int n = (int)g->ctx.size();
+    hipStream_t root = trh_internal::stream_of(g->ctx[0]);
+    HIP_TRY(hipSetDevice(trh_internal::device_of(g->ctx[0])));
+    for (int i = 0; i < n; ++i) {
+        size_t floats = 0;
+        float* acc = trh_internal::accum_of(g->ctx[(size_t)i], &floats);
+        if (floats != g->reduced_floats) return fail(TRH_ERR_STATE, "trh_group: members hold frames of different sizes");
+        if (i > 0) {
+            HIP_TRY(hipEventRecord(g->done[(size_t)i], trh_internal::stream_of(g->ctx[(size_t)i])));
+            HIP_TRY(hipStreamWaitEvent(root, g->done[(size_t)i], 0));
+        }
+        if (i == 0) {
+            HIP_TRY(hipMemcpyAsync(g->reduced, acc, floats * sizeof(float), hipMemcpyDeviceToDevice, root));
+        } else {
+            const uint32_t px = (uint32_t)(floats / 4);
+            hipLaunchKernelGGL(k_group_add, dim3((px + 255) / 256), dim3(256), 0, root, (float4*)g->reduced, (const float4*)acc, px);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    // the members must not render into their buffers before the sum has read them
+    HIP_TRY(hipEventRecord(g->done[0], root));
+    for (int i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(trh_internal::stream_of(g->ctx[(size_t)i]), g->done[0], 0));
+    return TRH_OK;
+}
+
 // the exchange step: sum of the per-device accumulation buffers into g->reduced on device 0
 int reduce_to_root(trh_group* g) {
+    if (g->alias) return sum_to_root_alias(g);
     const int n = (int)g->ctx.size();
     NCCL_TRY(g_rccl.GroupStart());
     for (int i = 0; i < n; ++i) {
@@ -299,7 +383,8 @@ extern "C" {
 int trh_group_resolve(trh_group* g, float* rgba_host, uint64_t* samples_out) {
     if (!g) return fail(TRH_ERR_INVALID_ARG, "trh_group_resolve: group is NULL");
     if (!g->has_scene) return fail(TRH_ERR_STATE, "trh_group_resolve: no scene");
-    if (!g->use_rccl) {
+    if (g->torn) return fail(TRH_ERR_STATE, "trh_group_resolve: an earlier render call failed part-way; call trh_group_reset_accumulation first");
+    if (!g->exchange) {
         if (int rc = trh_resolve(g->ctx[0], rgba_host, nullptr)) return rc;
     } else {
         if (int rc = reduce_to_root(g)) return rc;
@@ -314,7 +399,8 @@ int trh_group_resolve(trh_group* g, float* rgba_host, uint64_t* samples_out) {
 int trh_group_present_bgra8(trh_group* g, int tonemap, float exposure, uint32_t* bgra_host) {
     if (!g) return fail(TRH_ERR_INVALID_ARG, "trh_group_present_bgra8: group is NULL");
     if (!g->has_scene) return fail(TRH_ERR_STATE, "trh_group_present_bgra8: no scene");
-    if (!g->use_rccl) return trh_present_bgra8(g->ctx[0], tonemap, exposure, bgra_host);
+    if (g->torn) return fail(TRH_ERR_STATE, "trh_group_present_bgra8: an earlier render call failed part-way; call trh_group_reset_accumulation first");
+    if (!g->exchange) return trh_present_bgra8(g->ctx[0], tonemap, exposure, bgra_host);
     if (int rc = reduce_to_root(g)) return rc;
     if (int rc = trh_internal::present_from(g->ctx[0], g->reduced, tonemap, exposure, bgra_host)) return rc;
     for (size_t i = 1; i < g->ctx.size(); ++i)

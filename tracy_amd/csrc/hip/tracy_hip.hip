@@ -1804,6 +1804,7 @@ int fail(int code, const std::string& msg) { return ::fail(code, msg); }
 int device_of(const trh_context* c) { return c->device; }
 hipStream_t stream_of(const trh_context* c) { return c->stream; }
 int builder_of(const trh_context* c) { return c->builder; }
+bool can_render(const trh_context* c) { return c->has_scene && c->has_camera; }
 float* accum_of(const trh_context* c, size_t* float_count) {
     if (float_count) *float_count = (size_t)c->sc.width * c->sc.height * 4;
     return (float*)c->accum;
