@@ -1,5 +1,5 @@
 """Development aid (GPU): a few launches of one scene for rocprofv3 (tools/pmc_quick.sh).
-   python3 tools/prof_driver.py [scene] [spp] [launches] [max_bounces]"""
+   python3 tools/prof_driver.py [scene] [spp] [launches] [max_bounces] [pipeline]"""
 import os
 import sys
 
@@ -11,9 +11,9 @@ spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 w, h = (3840, 2160) if name == "helmet" else (1920, 1080)
 sc = Scene(f"data/scenes/{name}.scn", w, h)
-if len(sys.argv) > 4:
+if len(sys.argv) > 4 and int(sys.argv[4]) > 0:
     sc.desc.max_bounces = int(sys.argv[4])
-mod = HipTrace()
+mod = HipTrace(pipeline=int(sys.argv[5]) if len(sys.argv) > 5 else None)
 mod.Startup(sc)
 for k in range(n + 2):   # the first two launches (probe + first ordered launch) are warm-up
     mod.render(k * spp, spp)

@@ -1050,15 +1050,15 @@ int launch_wavefront(trh_context* c, const RenderParams& rp) {
     for (uint32_t done = 0; done < rp.spp_count; done += batch_spp) {
         const uint32_t spp = std::min(batch_spp, rp.spp_count - done);
         const uint32_t items = npix * spp;
-        WfCtl init{};
-        init.n_free = pool;
-        init.items_end = items;
-        HIP_TRY(hipMemcpyAsync(c->wf.ctl, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));   // `init` lives on this stack frame
-        hipLaunchKernelGGL(k_wf_init_free, pool_grid, dim3(256), 0, c->stream, c->wf.q_free, pool);
+        hipLaunchKernelGGL(k_wf_init_free, pool_grid, dim3(256), 0, c->stream, c->wf.q_free, pool, c->wf.ctl, items);
         uint32_t* q_cur = c->wf.q_a;
         uint32_t* q_next = c->wf.q_b;
         const uint32_t min_iters = items / pool;   // the item cursor cannot reach the end earlier
+        // The host only enqueues: the loop's end is a device-side condition (nothing queued, every item handed out) that the
+        // host looks at every kWfPoll iterations -- one small copy + one synchronisation per poll instead of one per
+        // iteration (round 2: the per-iteration round trip was part of the pipeline's time). Iterations past the end are
+        // launches of kernels that find their queues empty (a few microseconds each).
+        constexpr uint32_t kWfPoll = 8;
         for (uint32_t iter = 0;; ++iter) {
             hipLaunchKernelGGL(k_wf_generate, pool_grid, dim3(256), 0, c->stream, c->sc, c->wf, q_next, rp.spp_begin + done, rp.seed32);
             hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, c->stream, c->wf);
@@ -1067,7 +1067,7 @@ int launch_wavefront(trh_context* c, const RenderParams& rp) {
                                c->refill_thresh, c->sched_beta4);
             hipLaunchKernelGGL(k_wf_shade, dim3((pool + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, c->stream, c->sc, c->wf, q_cur, q_next, c->counters);
             HIP_TRY(hipGetLastError());
-            if (iter >= min_iters) {
+            if (iter >= min_iters && (iter - min_iters) % kWfPoll == kWfPoll - 1u) {
                 WfCtl h{};
                 HIP_TRY(hipMemcpyAsync(&h, c->wf.ctl, sizeof(h), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));

@@ -240,7 +240,15 @@ __global__ void k_wf_accumulate(const float4* __restrict__ item_rad, float4* __r
     accum[p] = a;
 }
 
-__global__ void k_wf_init_free(uint32_t* __restrict__ q_free, uint32_t n) {
+// start of a batch: every slot free, the item cursor at 0 (thread 0 also resets the control block: no host-side
+// staging buffer, no synchronisation before the first iteration)
+__global__ void k_wf_init_free(uint32_t* __restrict__ q_free, uint32_t n, WfCtl* __restrict__ ctl, uint32_t items) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) q_free[i] = i;
+    if (i == 0u) {
+        WfCtl c{};
+        c.n_free = n;
+        c.items_end = items;
+        *ctl = c;
+    }
 }
