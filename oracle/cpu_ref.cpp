@@ -752,6 +752,65 @@ void oref_sample_radiance(oref_scene* s, uint32_t sample_index, uint64_t seed, f
     }
 }
 
+// Diagnostic for the parity tests (no counterpart in the reference): the path of ONE (pixel, sample) bounce by bounce.
+// Per bounce iteration 6 floats: packed hit id (mesh << 24 | triangle, as bits; 0xffffffff = miss), t, and -- from a brute-
+// force pass over every triangle of the scene with a fresh RayT -- the candidate whose t is nearest to the hit's without
+// being the hit itself: its packed id (bits), its t, and the number of candidates within 1e-4 (relative) of the hit's t.
+// A path that differs between the module and the oracle on a bounce with such a rival is a "tie" difference (coincident or
+// touching faces: collision.h:66 keeps the last-tested one, and traversal order decides); one without is something else.
+uint32_t oref_trace_path(oref_scene* s, uint32_t px, uint32_t py, uint32_t sample_index, uint64_t seed, float* records, uint32_t max_records) {
+    const u32 idx = py * s->width + px;
+    u32 rng = path_rng_state(idx, sample_index, seed);
+    const float u = (px + fastrand(rng)) / float(s->width);
+    const float v = (py + fastrand(rng)) / float(s->height);
+    Ray ray = GetRayFrom(*s, u, v);
+    vec3 throughput{1.f, 1.f, 1.f};
+    u32 iters = 0;
+    for (u32 t = 0; t < s->max_bounces; ++t) {
+        HitData hit;
+        hit.t = FLT_MAX;
+        const bool any = ComputeIntersection(*s, ray, hit, nullptr);
+        float* rec = iters < max_records ? records + 6 * iters : nullptr;
+        ++iters;
+        if (rec) {
+            const u32 hid = any ? ((hit.object_index << 24) | (hit.triangle_index / 3)) : 0xffffffffu;
+            u32 rival = 0xffffffffu, close = 0;
+            float rival_t = 0.f, best = FLT_MAX;
+            if (any) {
+                for (u32 m = 0; m < (u32)s->meshes.size(); ++m)
+                    for (u32 ti = 0; ti < s->meshes[m].index_count; ti += 3) {
+                        const u32 id = (m << 24) | (ti / 3);
+                        if (id == hid) continue;
+                        TriangleHitData th{FLT_MAX, vec2{}};
+                        if (!RayTriangle(ray.origin, ray.direction, s->GetVertex(m, s->GetIndex(m, ti)).pos, s->GetVertex(m, s->GetIndex(m, ti + 1)).pos,
+                                         s->GetVertex(m, s->GetIndex(m, ti + 2)).pos, th)) continue;
+                        const float dt = std::fabs(th.RayT - hit.t);
+                        if (dt <= 1e-4f * hit.t) ++close;
+                        if (dt < best) { best = dt; rival = id; rival_t = th.RayT; }
+                    }
+            }
+            memcpy(rec + 0, &hid, 4);
+            rec[1] = any ? hit.t : 0.f;
+            memcpy(rec + 2, &rival, 4);
+            rec[3] = rival_t;
+            rec[4] = float(close);
+            rec[5] = 0.f;
+        }
+        if (!any) break;
+        vec3 attenuation, emission;
+        Ray next;
+        Scatter(*s, s->materials[hit.material], ray, hit, attenuation, emission, next, rng);
+        ray = next;
+        throughput *= attenuation;
+        if (s->flags & TRH_FLAG_RUSSIAN_ROULETTE) {
+            float p = EPS + fmax_(throughput.x, fmax_(throughput.y, throughput.z));
+            if (fastrand(rng) > p) break;
+            throughput *= rcp(p);
+        }
+    }
+    return iters;
+}
+
 // CpuTrace::OnUpdate (cpu_trace.cpp:33-70) called spp_count times: frame f traces sample
 // index spp_begin+f of every pixel and blends it with CPUDetails::UpdateOutput
 // (cpu_details.cpp:187-199). Pixel loop is x-major with idx = y*w+x as in the reference.

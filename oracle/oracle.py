@@ -96,6 +96,15 @@ class CpuRef:
         self.L.oref_sample_radiance(self._h, sample_index, seed, out.ctypes.data)
         return out
 
+    def trace_path(self, px, py, sample_index, seed=0xABCDEF, max_records=16):
+        """[(hit id, t, rival id, rival t, candidates within 1e-4 t)] per bounce iteration of one (pixel, sample)."""
+        rec = np.zeros((max_records, 6), dtype=np.float32)
+        self.L.oref_trace_path.restype = C.c_uint32
+        self.L.oref_trace_path.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32]
+        n = self.L.oref_trace_path(self._h, int(px), int(py), int(sample_index), int(seed), rec.ctypes.data, max_records)
+        ids = rec.view(np.uint32)
+        return [(int(ids[i, 0]), float(rec[i, 1]), int(ids[i, 2]), float(rec[i, 3]), int(rec[i, 4])) for i in range(min(n, max_records))]
+
     def render(self, spp_begin, spp_count, seed=0xABCDEF, count_traversal=False):
         self.L.oref_render(self._h, spp_begin, spp_count, seed, int(count_traversal))
 
