@@ -193,7 +193,9 @@ int trh_render(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, uint64_
 int trh_render_stats(trh_context* ctx, uint32_t spp_begin, uint32_t spp_count, uint64_t seed);
 
 /* trh_render for callers that cannot allocate. NO COUNTERPART IN THE REFERENCE: it exists for hosts that
- * run under HIP graph capture, in tight serving loops or in harnesses that forbid hipMalloc. Same samples, same
+ * may not call hipMalloc: tight serving loops, harnesses that forbid it, code that will run under HIP graph capture
+ * (capture itself is NOT exercised by the tests: the call also queries occupancy and sets the device, which a capturing
+ * host should check against its ROCm version). Same samples, same
  * kernels and the same launch sequence as trh_render with TRH_PIPELINE_MEGAKERNEL_LANES on a context that has no tile
  * order yet (every call of >= 16 spp traces its first sample as a launch of its own): bit-equal to that; equal to the
  * default pipeline up to the order of a pixel's float additions (the default pipeline's ring of paths is hipMalloc'ed

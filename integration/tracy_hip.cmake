@@ -48,4 +48,5 @@ if(NOT EXISTS ${TRACY_HIP_LIBRARY})
 	set(TRACY_HIP_NEEDS_BUILD ON)
 endif()
 list(APPEND tracy_libraries ${TRACY_HIP_LIBRARY} ${CMAKE_DL_LIBS})
-# (after add_executable: add_dependencies(${PROJECT_NAME} tracy_hip_library) when TRACY_HIP_NEEDS_BUILD is set)
+# (CMakeLists.patch adds, after add_executable: add_dependencies(${PROJECT_NAME} tracy_hip_library) when TRACY_HIP_NEEDS_BUILD is set --
+#  a full path in tracy_libraries creates no dependency on the custom command, and a parallel build could link too early)

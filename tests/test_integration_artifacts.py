@@ -29,6 +29,9 @@ def test_patches_apply_to_the_reference(tmp_path):
     assert "option(MODULE_HIP" in cm and "include(./ext/tracy_hip/tracy_hip.cmake)" in cm
     # the block sits with the other module blocks, before the executable is declared
     assert cm.index("if(MODULE_HIP)") < cm.index("add_executable(")
+    # ... and the executable waits for the library the fragment builds from source (a parallel build must not link before it exists)
+    assert "add_dependencies(${PROJECT_NAME} tracy_hip_library)" in cm
+    assert cm.index("add_executable(") < cm.index("add_dependencies(${PROJECT_NAME} tracy_hip_library)")
 
 
 def test_cmake_fragment_and_adapter_name_existing_files():

@@ -6,7 +6,7 @@
 //   radix sort    hipcub::DeviceRadixSort::SortPairs (code, triangle) -- stable, so equal codes keep input order
 //   clusters      (>= 4096 triangles) ranges that share their top 6..15 code bits; their boxes go to the host, which builds
 //                 the UPPER levels with binned SAH over the cluster boxes (TopBuilder) and seeds one range per cluster
-//   k_level       top-down over the sorted codes, one launch per tree level (<= 32): a range of > 4 triangles is
+//   k_level       top-down over the sorted codes, one launch per tree level (<= 32): a range of > 2 triangles (kLeafMax) is
 //                 split where the highest differing code bit flips (the LBVH split), or at its median when
 //                 the codes are equal or the remaining depth budget demands it (the depth guard of the host
 //                 builder: a Morton tree of a scene with one dense object in a large room is otherwise 40+
@@ -42,7 +42,7 @@ constexpr int kDepthAim = 27;             // see build(): the depth the guard ai
 #define TRH_LBVH_LEAF 2
 #endif
 constexpr uint32_t kLeafMax = TRH_LBVH_LEAF;
-constexpr float kCostTraverse = 0.5f;     // same constants as the host builder: sah_cost is comparable
+// (C_traverse comes from the host builder at run time, bvh::cost_traverse(): one constant, one scale for trh_bvh_info.sah_cost)
 constexpr float kCostIntersect = 1.0f;
 
 struct Tri { float v0[3], v1[3], v2[3]; uint32_t id; };
@@ -59,6 +59,7 @@ struct Frame {
     float cmn[3], cscale[3];   // Morton grid: q = (c - cmn) * cscale
     float scene_extent;        // padding term of the host builder
     float root_area_inv;
+    float cost_traverse;       // bvh::cost_traverse(): the host builder's C_traverse, so that sah_cost of the two builders is on one scale
     float frame_c[3];
     double frame_s;
 };
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(int n_inner, const int* __restr
     if (i < n_inner && live[i]) {
         Box b[2];
         int link[2];
-        sah += (double)(half_area(node_box[i]) * f.root_area_inv * kCostTraverse);
+        sah += (double)(half_area(node_box[i]) * f.root_area_inv * f.cost_traverse);
         for (int k = 0; k < 2; ++k) {
             const int c = child[2 * i + k];
             if (c < 0) {                          // <= kLeafMax triangles, contiguous in sorted order
@@ -524,6 +525,7 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     {
         const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
         f.root_area_inv = 1.f / std::max(dx * dy + dy * dz + dz * dx, 1e-30f);
+        f.cost_traverse = bvh::cost_traverse();
     }
 
     // ---- Morton codes, sort

@@ -635,4 +635,9 @@ uint64_t validate(const std::vector<InputTriangle>& tris, const Result& r, std::
     return bad;
 }
 
+float cost_traverse() {
+    if (const char* e = getenv("TRH_SAH_CT")) { const float v = (float)atof(e); if (v > 0.f) return v; }   // development knob, as in build()
+    return kCostTraverse;
+}
+
 }  // namespace bvh

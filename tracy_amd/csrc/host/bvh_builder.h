@@ -60,6 +60,10 @@ struct Result {
 
 void build(const std::vector<InputTriangle>& tris, Result& out);
 
+// C_traverse of the SAH (cost of one inner-record step in units of one triangle test; TRH_SAH_CT overrides it): shared with
+// the device-side builder so that Result::sah_cost / trh_bvh_info.sah_cost of the two builders are on one scale
+float cost_traverse();
+
 // On-disk cache of build results. build_cached() looks in `dir` for a file named after the
 // FNV-1a hash of the input triangles (and of the builder's constants and file-format version), checks its header,
 // sizes and a checksum of the arrays, and returns its contents; on a miss or any mismatch it builds, then writes the

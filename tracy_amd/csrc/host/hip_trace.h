@@ -200,7 +200,11 @@ public:
             auto_spp_ = static_cast<uint32_t>(ngpus_);   // react at once, then ramp up again
             camera_dirty_ = false;
         }
-        const uint32_t spp = spp_per_update_ ? spp_per_update_ : auto_spp_;
+        uint32_t spp = spp_per_update_ ? spp_per_update_ : auto_spp_;
+        // sample indices are 32 bits (trh_group_render refuses beyond): a static camera left alone for hours reaches the end of
+        // them at GPU rates (4096 spp per update). The last update is clamped and the picture then simply stays as it is.
+        if (spp > 0xffffffffu - next_sample_) spp = 0xffffffffu - next_sample_;
+        if (spp == 0) return;
         const auto t0 = std::chrono::steady_clock::now();
         Check(trh_group_render(group_, next_sample_, spp, kSeed), "trh_group_render");
         next_sample_ += spp;
@@ -223,11 +227,15 @@ public:
     // where the one exchange step runs (RCCL reduce to device 0).
     void OnRender(const WindowT in_Window) override {
         (void)in_Window;
-        Check(trh_group_present_bgra8(group_, tonemap_, exposure_, bitmap_.data()), "trh_group_present_bgra8");
-        if (unmeasured_spp_) {   // asynchronous updates: the present has waited for them
+        if (unmeasured_spp_) {
+            // asynchronous updates: wait for them HERE and adapt on the time the samples took, not on samples + present (round 2
+            // measured both together: the 8 MB picture copy counted as render time, the updates came out too small and the mode
+            // was slower than the synchronous one)
+            Check(trh_group_synchronize(group_), "trh_group_synchronize");
             Adapt(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - unmeasured_since_).count(), unmeasured_spp_);
             unmeasured_spp_ = 0;
         }
+        Check(trh_group_present_bgra8(group_, tonemap_, exposure_, bitmap_.data()), "trh_group_present_bgra8");
     }
 
     void OnEvent(EventT in_Event, const WindowT in_Window, const SceneT& in_Scene) override {
