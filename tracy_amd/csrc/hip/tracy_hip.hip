@@ -436,7 +436,7 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
                 has_path = cont;
             }
             {
-                const unsigned long long pmask = __ballot(has_path);
+                const unsigned long long pmask = __builtin_amdgcn_ballot_w64(has_path);
                 if (pmask != 0ull) {
                     if (has_path) {
                         const uint32_t idx = (tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u))) & qmask;
@@ -516,7 +516,7 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
                         has_ray = false;
                     }
                     if (head != tail) {
-                        const unsigned long long wmask = __ballot(want);
+                        const unsigned long long wmask = __builtin_amdgcn_ballot_w64(want);
                         if (want) {
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
                             if (rank < tail - head) {
@@ -530,15 +530,17 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
                             }
                         }
                         const uint32_t taken = (uint32_t)__popcll(wmask);
-                        head += taken < tail - head ? taken : tail - head;
+                        // (readfirstlane: the cursor is wave-uniform by construction, but updated under a condition on itself the
+                        // compiler cannot see through -- left alone it lives in a VGPR and every test of it becomes an exec-mask loop)
+                        head = (uint32_t)__builtin_amdgcn_readfirstlane((int)(head + (taken < tail - head ? taken : tail - head)));
                     }
-                    const uint32_t nR = (uint32_t)__popcll(__ballot(has_ray));
+                    const uint32_t nR = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_ray));
                     if (nR == 0u) break;   // ready rays used up (a lane without a ray found none), every hit stored
                     // leave the vote loop when refill_thresh lanes have finished -- or all of them, once nothing is left to take
-                    const uint32_t wait_limit = (head != tail && rp.refill_thresh < nR) ? rp.refill_thresh : nR;
+                    const uint32_t wait_limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)((head != tail && rp.refill_thresh < nR) ? rp.refill_thresh : nR));
                     for (;;) {
-                        const uint32_t nI = (uint32_t)__popcll(__ballot(tv.node >= 0));
-                        const uint32_t nL = (uint32_t)__popcll(__ballot(tv.node < -1));
+                        const uint32_t nI = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tv.node >= 0));
+                        const uint32_t nL = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tv.node < -1));
                         if (nR - (nI + nL) >= wait_limit) break;
                         const unsigned long long t_step = STATS ? __builtin_readcyclecounter() : 0ull;
                         if (nI * 4u >= nL * rp.sched_beta4) {
