@@ -19,8 +19,13 @@
 #include "dev_types.h"
 
 #define DEVFN __device__ __forceinline__
+#define TRH_SCALAR_AS __attribute__((address_space(4)))   // constant address space: a load from a wave-uniform address becomes s_load
 
 namespace dev {
+
+typedef uint32_t U32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t U32x16 __attribute__((ext_vector_type(16)));
+typedef float F32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float PI = 3.1415926535897932f;
 constexpr float EPS = 1.e-8f;
@@ -118,9 +123,13 @@ DEVFN void camera_ray(const DevScene& sc, float s, float t, V3& o, V3& d) {
 //     beats the earlier mesh a iff t_b <= t_a and slab_tmin(AABB_b) < t_a. This is what decides
 //     coincident coplanar faces of two objects (data/scenes/random.scn: light box on a wall).
 DEVFN bool accept_candidate(const DevScene& sc, V3 o, V3 d, float t, uint32_t id, const Hit& hit) {
-    if (t < EPS) return false;
     const uint32_t mc = id >> 24, mh = hit.id >> 24;
-    if (mc == mh || !(fabsf(t - hit.t) <= 1e-5f * hit.t)) return t < hit.t || (t == hit.t && id > hit.id);
+    // the common outcome without branches (bitwise operators: short-circuit forms become a chain of exec-mask regions);
+    // only a candidate of ANOTHER mesh within 1e-5 t of the hit enters the replay of the reference's pairwise rule below
+    const bool plain = (mc == mh) | !(fabsf(t - hit.t) <= 1e-5f * hit.t);
+    const bool nearer = !(t < EPS) & ((t < hit.t) | ((t == hit.t) & (id > hit.id)));
+    if (plain) return nearer;
+    if (t < EPS) return false;
     const bool c_later = mc > mh;
     const float t_a = c_later ? hit.t : t;
     const float t_b = c_later ? t : hit.t;
@@ -290,13 +299,13 @@ DEVFN void tri_test(const DevScene& sc, V3 o, V3 d, float4 r0, float4 r1, float4
     if (ok) {
         const float rdet = 1.f / det;
         const float t = dot_f(e2, qvec) * rdet;
-        if (accept_candidate(sc, o, d, t, id, hit)) {
-            hit.t = t;
-            hit.u = u * rdet;
-            hit.v = v * rdet;
-            hit.prim = (int)p;
-            hit.id = id;
-        }
+        // selects, not a second branch: most candidates that reach this point are accepted
+        const bool a = accept_candidate(sc, o, d, t, id, hit);
+        hit.t = a ? t : hit.t;
+        hit.u = a ? u * rdet : hit.u;
+        hit.v = a ? v * rdet : hit.v;
+        hit.prim = a ? (int)p : hit.prim;
+        hit.id = a ? id : hit.id;
     }
 }
 
@@ -332,10 +341,6 @@ DEVFN void trav_leaf(const DevScene& sc, V3 o, V3 d, Trav& tv, int* __restrict__
 // a box its own ray misses cannot be hit (the box holds the triangle), so each lane ends with the same nearest hit as
 // its own traversal would find (same candidate rule, accept_candidate). Meant for camera rays of one pixel or of a few
 // neighbouring pixels: the union of their walks is hardly larger than each walk, and no lane waits for another.
-typedef uint32_t U32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t U32x16 __attribute__((ext_vector_type(16)));
-typedef float F32x4 __attribute__((ext_vector_type(4)));
-#define TRH_SCALAR_AS __attribute__((address_space(4)))   // constant address space: a wave-uniform address becomes s_load
 
 // lane `index` of a VGPR as one element of a wave-uniform array (index and value wave-uniform)
 DEVFN uint32_t write_lane(uint32_t v, uint32_t index, uint32_t value) {
@@ -492,7 +497,16 @@ DEVFN bool shade(const DevScene& sc, PathState& ps, const Hit& hit, Counters& cn
         V3 normal = w * n0 + hit.u * n1 + hit.v * n2;
         const float tu = w * s2.y + hit.u * s2.w + hit.v * s3.y;
         const float tv = w * s2.z + hit.u * s3.x + hit.v * s3.z;
-        const DevMaterial m = sc.materials[__float_as_uint(s3.w)];
+        // Scenes have a handful of materials and the lanes of a shade call mostly hit the same one (camera rays of one pixel,
+        // bounce rays of a few neighbours): then the 64-byte record comes through the scalar cache -- one request for the
+        // wave and a shorter wait than the third dependent vector round trip of this function
+        const uint32_t mid = __float_as_uint(s3.w);
+        const uint32_t mid0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mid);
+        DevMaterial m;
+        if (__builtin_amdgcn_ballot_w64(mid != mid0) == 0ull)
+            m = __builtin_bit_cast(DevMaterial, *reinterpret_cast<const TRH_SCALAR_AS U32x16*>(reinterpret_cast<uintptr_t>(sc.materials) + (size_t)mid0 * sizeof(DevMaterial)));
+        else
+            m = sc.materials[mid];
 
         // ---- texture-or-constant (src/material.h:164-203), in Scatter's order (:217-221)
         V3 emissive = mk(m.emissive[0], m.emissive[1], m.emissive[2]);
@@ -565,7 +579,7 @@ DEVFN bool shade(const DevScene& sc, PathState& ps, const Hit& hit, Counters& cn
         ps.throughput = ps.throughput * attenuation;           // cpu_trace.cpp:143
     } else {
         // ---- sky (cpu_trace.cpp:146-156)
-        const DevMaterial sky = sc.materials[0];
+        const DevMaterial sky = __builtin_bit_cast(DevMaterial, *reinterpret_cast<const TRH_SCALAR_AS U32x16*>(reinterpret_cast<uintptr_t>(sc.materials)));   // material 0 (scene.h:21,67), through the scalar cache
         V3 emission = mk(sky.emissive[0], sky.emissive[1], sky.emissive[2]);
         if (sky.tex[4] != TRH_MISS_ID) {
             const float su = atan2f(ps.d.z, ps.d.x) / (2 * PI) + 0.5f;

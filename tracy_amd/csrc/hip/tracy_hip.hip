@@ -426,7 +426,7 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
             const unsigned long long t_phase0 = STATS ? __builtin_readcyclecounter() : 0ull;
             if (has_path) {
                 const bool cont = shade<STATS>(sc, ps, hit, cnt);
-                if (ps.radiance.x != 0.f || ps.radiance.y != 0.f || ps.radiance.z != 0.f) {
+                if ((ps.radiance.x != 0.f) | (ps.radiance.y != 0.f) | (ps.radiance.z != 0.f)) {
                     float* const lane_acc = wacc + ((fresh_lane_id() & (rp.acc_copies - 1u)) * acc_stride + pix * 3u);
                     __hip_atomic_fetch_add(&lane_acc[0], ps.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&lane_acc[1], ps.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
