@@ -457,6 +457,9 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
                 if (i - shade_head < left) {
                     const uint32_t idx = i & qmask;
                     const float4 a = qa[idx], b = qb[idx], c = qc[idx], h = qh[idx];
+#if defined(TRH_MEASURE_RING_STALL)   // development: how long does a shade batch wait for its ring entries?
+                    if (STATS) { const unsigned long long t0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (fresh_lane_id() == 0u) cnt.idle_none += (uint32_t)((__builtin_readcyclecounter() - t0) >> 4); }
+#endif
                     ps.o = mk(a.x, a.y, a.z);
                     ps.d = mk(a.w, b.x, b.y);
                     ps.throughput = mk(b.z, b.w, c.x);
@@ -523,6 +526,9 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
                                 slot = (head + rank) & qmask;
                                 const float4 a = qa[slot];
                                 const float2 b = *reinterpret_cast<const float2*>(&qb[slot]);
+#if defined(TRH_MEASURE_RING_STALL)   // development: ... and a refill of the traverse phase for its rays?
+                                if (STATS) { const unsigned long long t0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (first_active_lane()) cnt.idle_wait += (uint32_t)((__builtin_readcyclecounter() - t0) >> 4); }
+#endif
                                 ro = mk(a.x, a.y, a.z);
                                 rd = mk(a.w, b.x, b.y);
                                 trav_begin(sc, tv, ro, rd, stack_column(s_dyn, tv.top));
@@ -544,7 +550,9 @@ void k_megakernel_ab(DevScene sc, RenderParams rp, float4* __restrict__ accum, D
                         if (nR - (nI + nL) >= wait_limit) break;
                         const unsigned long long t_step = STATS ? __builtin_readcyclecounter() : 0ull;
                         if (nI * 4u >= nL * rp.sched_beta4) {
+                            #if !defined(TRH_MEASURE_RING_STALL)
                             if (STATS && fresh_lane_id() == 0u) { cnt.idle_leaf += nL; cnt.idle_wait += nR - nI - nL; cnt.idle_none += 64u - nR; }
+#endif
 #pragma unroll
                             for (int r = 0; r < TRH_INNER_REPEAT; ++r)
                                 if (tv.node >= 0) trav_inner<STATS, N16>(sc, ro, tv, nullptr, cnt);
