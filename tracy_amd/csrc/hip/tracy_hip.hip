@@ -1291,6 +1291,7 @@ int scene_upload_impl(trh_context* c, const trh_scene_desc* d, const bvh::Result
     if (d->mesh_count > 256) return fail(TRH_ERR_LIMIT, "trh_scene_upload: more than 256 meshes (8-bit mesh id)");
     if (d->material_count == 0) return fail(TRH_ERR_INVALID_ARG, "trh_scene_upload: material 0 (sky) is required");
     if ((uint64_t)d->width * d->height > (1ull << 31)) return fail(TRH_ERR_LIMIT, "trh_scene_upload: frame too large");
+    if (d->max_bounces >= (1u << 24)) return fail(TRH_ERR_LIMIT, "trh_scene_upload: max_bounces must be below 2^24 (a path's bounce count shares a word with its pixel in the ring)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_scene(c);
