@@ -27,5 +27,5 @@ for scene in scenes:
         print(f"{scene} cap/target/refill {cfg}: {ms:.2f} ms | traverse-phase util inner {ui:.3f} leaf {ul:.3f}; shade util {us:.3f} | "
               f"idle at inner vote: leaf {d['idle_leaf_in_inner']/votes:.3f} finished {d['idle_wait_in_inner']/votes:.3f} no-ray {d['idle_none_in_inner']/votes:.3f} | "
               f"time: inner {d['cycles_inner']/k:.3f} leaf {d['cycles_leaf']/k:.3f} shade+push {d['cycles_shade']/k:.3f} camera {d['cycles_refill']/k:.3f} rest {rest/k:.3f} | "
-              f"secondary rays: box/ray {st['box_tests']/max(1, st['rays'] - d['lanes_gen']):.1f}", flush=True)
+              f"secondary rays: box/ray {st['box_tests']/max(1, st['rays'] - d['lanes_gen']):.1f} | Gcycles inner {d['cycles_inner']/1e9:.3f} leaf {d['cycles_leaf']/1e9:.3f} kernel {k/1e9:.3f}", flush=True)
         mod.Shutdown()
