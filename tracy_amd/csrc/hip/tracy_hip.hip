@@ -901,9 +901,11 @@ void choose_tiling(const trh_context* c, uint32_t spp_count, uint32_t& wl, uint3
     // 128-pixel tiles 20.0 ms, 32-pixel tiles 18.1)
     const double p_wish = std::min(std::min(items_wish / (double)spp_count, pixels / (resident_waves * 16.0)), spp_count >= 64u ? 32.0 : 256.0);
     uint32_t p_log2 = 2;
+    static const int forced = [] { const char* e = getenv("TRH_TILE_PLOG2"); return e ? atoi(e) : -1; }();   // development knob
     while (p_log2 < 8u && (double)(2u << p_log2) <= p_wish * 1.4142135) ++p_log2;   // nearest power of two
     // few samples: rather 512 items per tile than 16 tiles per wave, down to 4 tiles per wave
     while (p_log2 < 8u && (uint64_t)(1u << p_log2) * spp_count < 512u && pixels / (double)(2u << p_log2) >= resident_waves * 4.0) ++p_log2;
+    if (forced >= 2 && forced <= 8) p_log2 = (uint32_t)forced;
     wl = (p_log2 + 1u) / 2u;
     hl = p_log2 / 2u;
     ntiles = (((uint32_t)c->sc.width + (1u << wl) - 1u) >> wl) * (((uint32_t)c->sc.height + (1u << hl) - 1u) >> hl);
