@@ -4,16 +4,18 @@
 //   k_bounds      scene box + centroid box: wave reduction, then ordered-integer atomic min / max
 //   k_morton      63-bit Morton code of every centroid (21 bits per axis inside the centroid box)
 //   radix sort    hipcub::DeviceRadixSort::SortPairs (code, triangle) -- stable, so equal codes keep input order
-//   clusters      (>= 4096 triangles) ranges that share their top 6..15 code bits; their boxes go to the host, which builds
-//                 the UPPER levels with binned SAH over the cluster boxes (TopBuilder) and seeds one range per cluster
-//   k_level       top-down over the sorted codes, one launch per tree level (<= 32): a range of > 2 triangles (kLeafMax) is
+//   clusters      (>= 4096 triangles) ranges that share their top 6..21 code bits (about two triangles each): boxes by one kernel
+//   k_top_level   the UPPER levels: binned SAH over the cluster boxes, one launch per level, one workgroup per node (round 3:
+//                 on the device; 12 bytes -- cluster count, biggest cluster -- are all the host reads); one seed range per cluster
+//   k_level_sah   below the seeds: binned SAH again, one wave per range, one launch per generation of the work queue
+//   (k_level      TRH_LBVH_SPLIT=morton, kept for A/B: the linear BVH's splits -- a range of > 2 triangles (kLeafMax) is
 //                 split where the highest differing code bit flips (the LBVH split), or at its median when
 //                 the codes are equal or the remaining depth budget demands it (the depth guard of the host
 //                 builder: a Morton tree of a scene with one dense object in a large room is otherwise 40+
 //                 levels deep); the inner node is stored at its split position, which is unique, so the
 //                 layout does not depend on the order the work queue fills. A range of <= 2 triangles is a
 //                 leaf: its thread computes the box and walks up; the second thread to arrive at a node
-//                 merges the child boxes (acquire/release counter per node)
+//                 merges the child boxes (acquire/release counter per node))
 //   scan          exclusive sum over the created nodes = compacted record index (the root is moved to record 0)
 //   k_emit        64-byte fp32 and 32-byte fp16 records (layouts in bvh_builder.h), boxes padded and rounded
 //                 outward exactly as the host builder does; sub-trees of <= 2 triangles become leaf links
@@ -34,7 +36,6 @@ namespace lbvh {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kLinkUnknown = (int)0x80000000;   // k_scatter_top: a child link the linear build fills in
 constexpr int kDepthAim = 27;             // see build(): the depth the guard aims for
 // triangles per leaf (the link format allows bvh::kMaxLeafSize = 8). Swept with the SAH top tree in place (64 spp per launch,
 // dragon / spheres / dragon 400 k): 1: 12.00 / 7.47 / 16.0 ms, 2: 11.54 / 7.18 / 13.8, 3: 11.66 / 7.28, 4: 11.91 / 7.52 / 15.5, 6: 13.02 / 7.92
@@ -155,11 +156,14 @@ __global__ __launch_bounds__(kBlock) void k_cluster_starts(const uint32_t* __res
     if (i >= n) return;
     if (flags[i]) starts[index[i]] = i;
 }
-__global__ __launch_bounds__(kBlock) void k_cluster_boxes(const Tri* __restrict__ tris, const uint32_t* __restrict__ prim, const uint32_t* __restrict__ starts, uint32_t n_clusters,
-                                                          uint32_t n, Box* __restrict__ boxes) {
+// (the number of clusters is still on the device when this is launched: flags[n - 1] + index[n - 1]; the grid covers the upper bound)
+__global__ __launch_bounds__(kBlock) void k_cluster_boxes(const Tri* __restrict__ tris, const uint32_t* __restrict__ prim, const uint32_t* __restrict__ starts, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ index,
+                                                          uint32_t n, Box* __restrict__ boxes, uint32_t* __restrict__ biggest) {
     const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_clusters = flags[n - 1u] + index[n - 1u];
     if (c >= n_clusters) return;
     const uint32_t lo = starts[c], hi = c + 1u < n_clusters ? starts[c + 1u] : n;
+    if (hi - lo > __hip_atomic_load(biggest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(biggest, hi - lo);
     Box b = tri_box(tris[prim[lo]]);
     for (uint32_t p = lo + 1u; p < hi; ++p) {
         const Box t = tri_box(tris[prim[p]]);
@@ -168,24 +172,168 @@ __global__ __launch_bounds__(kBlock) void k_cluster_boxes(const Tri* __restrict_
     boxes[c] = b;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scatter_top(const int* __restrict__ ids, const int* __restrict__ parents, const int* __restrict__ children, int n_top,
-                                                        int* __restrict__ parent, int* __restrict__ child, uint32_t* __restrict__ live) {
-    const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (t >= n_top) return;
-    const int id = ids[t];
-    parent[id] = parents[t];
-    live[id] = 1u;
-    // links to cluster ranges are written by the linear build (k_level); only links between top nodes are known here
-    if (children[2 * t] != kLinkUnknown) child[2 * id] = children[2 * t];
-    if (children[2 * t + 1] != kLinkUnknown) child[2 * id + 1] = children[2 * t + 1];
-}
-
 struct Item { int lo, hi, parent, side, depth; };   // a range of sorted positions, the node above it, which child it is, the depth of the record it would become
 
 __host__ __device__ inline int levels_needed(uint32_t n) {   // record levels a median-split sub-tree of n triangles needs
     int l = 0;
     while (n > kLeafMax) { n = (n + 1) / 2; ++l; }
     return l;
+}
+
+// ---- SAH top tree over the Morton clusters, on the device (round 3; round 2 built it with one host thread after two round trips).
+// The Morton curve clusters the upper levels of a scene badly (a split at the highest differing bit is a spatial-median
+// split, whatever the geometry), and that is where a linear BVH loses against SAH; inside a small cluster the difference
+// is nil. So the upper levels are built with binned SAH (16 bins per axis, cost = half area x triangle count)
+// over the cluster boxes, level by level: one launch per level, one workgroup per node of the level. A node owns a
+// range of `order` (cluster indices, Morton order to begin with); the workgroup bins it (LDS atomics on ordered
+// integers), one thread sweeps the 3 x 15 candidate planes with the host builder's rule -- first minimum wins, both
+// sides must still fit below max_seed_depth -- and the range is stably partitioned into the level's output array (ballot +
+// prefix counts), so the result does not depend on thread timing. A node takes cluster (mid - 1)'s last sorted position
+// as its index (mid = its split position in `order`: unique, and the linear build never uses a cluster's last position);
+// a side of ONE cluster becomes a seed range of the linear build (k_level), a larger side an item of the next level.
+struct TopItem { int begin, end, parent, side, depth; };
+
+__global__ __launch_bounds__(kBlock) void k_iota(int* __restrict__ out, int n) {
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (i < n) out[i] = i;
+}
+
+__device__ inline int ceil_log2_u32(uint32_t k) { int l = 0; while ((1u << l) < k) ++l; return l; }
+
+__global__ __launch_bounds__(kBlock) void k_top_level(const TopItem* __restrict__ items, const unsigned int* __restrict__ item_count, TopItem* __restrict__ next_items,
+                                                      unsigned int* __restrict__ next_count, const int* __restrict__ order_in, int* __restrict__ order_out,
+                                                      const Box* __restrict__ cboxes, const uint32_t* __restrict__ starts, uint32_t n_clusters, uint32_t n, int max_seed_depth,
+                                                      Item* __restrict__ seeds, unsigned int* __restrict__ seed_count, Stats* __restrict__ stats,
+                                                      int* __restrict__ parent, int* __restrict__ child, uint32_t* __restrict__ live, int* __restrict__ root_out) {
+    constexpr int B = 16;
+    if (blockIdx.x >= *item_count) return;
+    const TopItem it = items[blockIdx.x];
+    const int k = it.end - it.begin;   // >= 2
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t s_cb[6];                 // centroid bounds, ordered
+    __shared__ uint32_t s_bb[3][B][6];           // bin boxes, ordered
+    __shared__ uint32_t s_cnt[3][B], s_num[3][B];
+    __shared__ int s_axis, s_bin, s_left;
+    __shared__ int s_wl[kBlock / 64];            // left elements per wave of the current chunk
+    __shared__ int s_id;
+    for (int i = tid; i < 3 * B * 6; i += kBlock) (&s_bb[0][0][0])[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+    for (int i = tid; i < 3 * B; i += kBlock) { (&s_cnt[0][0])[i] = 0u; (&s_num[0][0])[i] = 0u; }
+    if (tid < 6) s_cb[tid] = tid < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
+    auto cluster_count = [&](int c) { return ((uint32_t)c + 1u < n_clusters ? starts[c + 1] : n) - starts[c]; };
+    // ---- bounds of the centroids
+    {
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = it.begin + tid; i < it.end; i += kBlock) {
+            const Box b = cboxes[order_in[i]];
+            for (int a = 0; a < 3; ++a) { const float c = 0.5f * (b.mn[a] + b.mx[a]); mn[a] = fminf(mn[a], c); mx[a] = fmaxf(mx[a], c); }
+        }
+        for (int a = 0; a < 3; ++a) {
+            for (int off = 32; off > 0; off >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64)); }
+            if (lane == 0) { atomicMin(&s_cb[a], float_to_ordered(mn[a])); atomicMax(&s_cb[3 + a], float_to_ordered(mx[a])); }
+        }
+    }
+    __syncthreads();
+    float cmn[3], ext[3], scale[3];
+    for (int a = 0; a < 3; ++a) {
+        cmn[a] = ordered_to_float(s_cb[a]);
+        ext[a] = ordered_to_float(s_cb[3 + a]) - cmn[a];
+        scale[a] = ext[a] > 0.f ? (float)B / ext[a] : 0.f;
+    }
+    auto bin_of = [&](const Box& b, int a) { const float c = 0.5f * (b.mn[a] + b.mx[a]); const int x = (int)((c - cmn[a]) * scale[a]); return x < 0 ? 0 : (x > B - 1 ? B - 1 : x); };
+    // ---- bins
+    for (int i = it.begin + tid; i < it.end; i += kBlock) {
+        const int c = order_in[i];
+        const Box b = cboxes[c];
+        const uint32_t cnt = cluster_count(c);
+        for (int a = 0; a < 3; ++a) {
+            if (!(ext[a] > 0.f)) continue;
+            const int x = bin_of(b, a);
+            for (int d = 0; d < 3; ++d) { atomicMin(&s_bb[a][x][d], float_to_ordered(b.mn[d])); atomicMax(&s_bb[a][x][3 + d], float_to_ordered(b.mx[d])); }
+            atomicAdd(&s_cnt[a][x], cnt);
+            atomicAdd(&s_num[a][x], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- the sweep (one thread: 45 candidate planes)
+    if (tid == 0) {
+        float best = FLT_MAX;
+        int best_axis = -1, best_bin = -1, best_left = 0;
+        for (int a = 0; a < 3; ++a) {
+            if (!(ext[a] > 0.f)) continue;
+            float rarea[B];
+            uint32_t rcnt[B], rnum[B];
+            Box acc;
+            for (int x = 0; x < 3; ++x) { acc.mn[x] = FLT_MAX; acc.mx[x] = -FLT_MAX; }
+            uint32_t c = 0, m = 0;
+            for (int b = B - 1; b > 0; --b) {
+                if (s_num[a][b]) for (int x = 0; x < 3; ++x) { acc.mn[x] = fminf(acc.mn[x], ordered_to_float(s_bb[a][b][x])); acc.mx[x] = fmaxf(acc.mx[x], ordered_to_float(s_bb[a][b][3 + x])); }
+                c += s_cnt[a][b]; m += s_num[a][b];
+                rarea[b] = half_area(acc); rcnt[b] = c; rnum[b] = m;
+            }
+            Box lacc;
+            for (int x = 0; x < 3; ++x) { lacc.mn[x] = FLT_MAX; lacc.mx[x] = -FLT_MAX; }
+            uint32_t lc = 0, lm = 0;
+            for (int b = 0; b < B - 1; ++b) {
+                if (s_num[a][b]) for (int x = 0; x < 3; ++x) { lacc.mn[x] = fminf(lacc.mn[x], ordered_to_float(s_bb[a][b][x])); lacc.mx[x] = fmaxf(lacc.mx[x], ordered_to_float(s_bb[a][b][3 + x])); }
+                lc += s_cnt[a][b]; lm += s_num[a][b];
+                if (lm == 0 || rnum[b + 1] == 0) continue;
+                // depth guard: both sides must still fit below max_seed_depth
+                if (it.depth + 1 + ceil_log2_u32(lm > rnum[b + 1] ? lm : rnum[b + 1]) > max_seed_depth) continue;
+                const float cost = half_area(lacc) * (float)lc + rarea[b + 1] * (float)rcnt[b + 1];
+                if (cost < best) { best = cost; best_axis = a; best_bin = b; best_left = (int)lm; }
+            }
+        }
+        s_axis = best_axis;
+        s_bin = best_bin;
+        s_left = best_axis >= 0 ? best_left : k / 2;   // no plane (equal centroids, or the depth guard): the median of the range as it stands
+        // this node
+        const int mid = it.begin + s_left;
+        const int id = (int)(((uint32_t)mid < n_clusters ? starts[mid] : n) - 1u);   // cluster (mid - 1)'s last sorted position
+        s_id = id;
+        parent[id] = it.parent;
+        live[id] = 1u;
+        if (it.parent >= 0) child[2 * it.parent + it.side] = id; else *root_out = id;
+        if ((uint32_t)it.depth > __hip_atomic_load(&stats->max_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats->max_depth, (uint32_t)it.depth);
+        const int nl = s_left, nr = k - s_left;
+        if (nl > 1) { const unsigned int pos = atomicAdd(next_count, 1u); next_items[pos] = TopItem{it.begin, mid, id, 0, it.depth + 1}; }
+        if (nr > 1) { const unsigned int pos = atomicAdd(next_count, 1u); next_items[pos] = TopItem{mid, it.end, id, 1, it.depth + 1}; }
+    }
+    __syncthreads();
+    // ---- stable partition into order_out; a side of one cluster becomes a seed of the linear build
+    const int axis = s_axis, bin = s_bin, nl = s_left, id = s_id;
+    int run_l = 0, run_r = 0;   // elements of the chunks before this one (the same in every thread)
+    for (int base = it.begin; base < it.end; base += kBlock) {
+        const int i = base + tid;
+        const bool in = i < it.end;
+        int c = 0;
+        bool left = false;
+        if (in) {
+            c = order_in[i];
+            left = axis >= 0 ? bin_of(cboxes[c], axis) <= bin : (i - it.begin) < nl;
+        }
+        const unsigned long long ml = __ballot(in && left);
+        if (lane == 0) s_wl[wave] = (int)__popcll(ml);
+        __syncthreads();
+        int before_l = 0, total_l = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) before_l += s_wl[w]; total_l += s_wl[w]; }
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const int my_l = before_l + (int)__popcll(ml & below);   // left elements of this chunk before this thread's
+        if (in) {   // (the threads of a chunk that hold an element are 0 .. chunk - 1: tid elements come before this one)
+            const int pos = left ? it.begin + run_l + my_l : it.begin + nl + run_r + (tid - my_l);
+            order_out[pos] = c;
+            const bool alone = (left && nl == 1) || (!left && k - nl == 1);
+            if (alone) {
+                const uint32_t lo = starts[c], hi = ((uint32_t)c + 1u < n_clusters ? starts[c + 1] : n) - 1u;
+                const unsigned int sp = atomicAdd(seed_count, 1u);
+                seeds[sp] = Item{(int)lo, (int)hi, id, left ? 0 : 1, it.depth + 1};
+            }
+        }
+        const int chunk = it.end - base < kBlock ? it.end - base : kBlock;
+        run_l += total_l;
+        run_r += chunk - total_l;
+        __syncthreads();
+    }
 }
 
 // child links: >= 0 inner node (index = its split position), < -1 leaf ~((first << 4) | count)
@@ -248,6 +396,175 @@ __global__ __launch_bounds__(kBlock) void k_level(const Item* __restrict__ items
         }
         node_box[node] = u;
         node = parent[node];
+    }
+}
+
+// ---- binned-SAH splits below the top tree (round 3; the Morton splits of k_level are kept for A/B, TRH_LBVH_SPLIT=morton).
+// The ranges the top tree leaves (one per Morton cluster, tens of triangles) and every range below them are split like the
+// host builder splits: 16 bins per axis over the triangle centres, cost = half area x triangle count, first minimum wins;
+// the depth guard of k_level applies to every candidate plane (both sides must still be finishable by medians), and a
+// range without a valid plane is cut at its median position. One WAVE per range: bins in the wave's LDS block (atomics on
+// ordered integers), 45 lanes evaluate the 45 planes, stable partition by ballot + prefix count from `prim_in` into
+// `prim_out` (the arrays alternate between generations; a leaf copies its triangles to `prim_final`, the order the triangle
+// records are emitted in). Node index = split position, as in k_level: unique, so the layout does not depend on the order
+// of the work queue. Sides of <= kLeafMax triangles become leaves at once (box, link, bottom-up merge), larger ones are
+// queued for the next generation.
+struct WaveBins { uint32_t bb[3][16][6]; uint32_t num[3][16]; };
+
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// a leaf over the sorted positions [lo, hi] (one lane): final order, box, link, then up the tree as far as this lane is the second to arrive
+__device__ inline void make_leaf(int lo, int hi, int par, int side, const Tri* __restrict__ tris, const uint32_t* prim_src, uint32_t* prim_final,
+                                 int* parent, int* child, Box* leaf_box, Box* node_box, unsigned int* arrived) {
+    Box b;
+    for (int p = lo; p <= hi; ++p) {
+        const uint32_t t = prim_src[p];
+        prim_final[p] = t;
+        const Box tb = tri_box(tris[t]);
+        for (int a = 0; a < 3; ++a) {
+            b.mn[a] = p == lo ? tb.mn[a] : fminf(b.mn[a], tb.mn[a]);
+            b.mx[a] = p == lo ? tb.mx[a] : fmaxf(b.mx[a], tb.mx[a]);
+        }
+    }
+    leaf_box[lo] = b;
+    child[2 * par + side] = ~(int)(((uint32_t)lo << 4) | (uint32_t)(hi - lo + 1));
+    int node = par;
+    while (node >= 0) {
+        // release this lane's box and link, acquire the sibling's: the second to arrive carries on
+        const unsigned int old = __hip_atomic_fetch_add(&arrived[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0u) return;
+        Box u;
+        for (int sd = 0; sd < 2; ++sd) {
+            const int link = child[2 * node + sd];
+            const Box c = link < 0 ? leaf_box[(~(uint32_t)link) >> 4] : node_box[link];
+            for (int a = 0; a < 3; ++a) {
+                u.mn[a] = sd ? fminf(u.mn[a], c.mn[a]) : c.mn[a];
+                u.mx[a] = sd ? fmaxf(u.mx[a], c.mx[a]) : c.mx[a];
+            }
+        }
+        node_box[node] = u;
+        node = parent[node];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_level_sah(const Item* __restrict__ items, const unsigned int* __restrict__ item_count, Item* __restrict__ next_items,
+                                                      unsigned int* __restrict__ next_count, int depth_limit, const Tri* __restrict__ tris, const uint32_t* prim_in,
+                                                      uint32_t* prim_out, uint32_t* prim_final, Stats* __restrict__ stats, int* parent, int* child,
+                                                      uint32_t* __restrict__ live, Box* leaf_box, Box* node_box, unsigned int* arrived, int* __restrict__ root_out) {
+    constexpr int B = 16;
+    __shared__ WaveBins s_bins[kBlock / 64];
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    WaveBins& wb = s_bins[wave];
+    const unsigned int count = *item_count;
+    const unsigned int total_waves = gridDim.x * (unsigned)(kBlock / 64);
+    for (unsigned int k = blockIdx.x * (unsigned)(kBlock / 64) + (unsigned)wave; k < count; k += total_waves) {
+        const Item it = items[k];
+        const int m = it.hi - it.lo + 1;
+        if ((uint32_t)m <= kLeafMax) {   // (a seed range as small as a leaf)
+            if (lane == 0) make_leaf(it.lo, it.hi, it.parent, it.side, tris, prim_in, prim_final, parent, child, leaf_box, node_box, arrived);
+            continue;
+        }
+        // ---- bounds of the centres
+        float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = it.lo + lane; i <= it.hi; i += 64) {
+            const Box b = tri_box(tris[prim_in[i]]);
+            for (int a = 0; a < 3; ++a) { const float c = 0.5f * (b.mn[a] + b.mx[a]); cmn[a] = fminf(cmn[a], c); cmx[a] = fmaxf(cmx[a], c); }
+        }
+        float ext[3], scale[3];
+        for (int a = 0; a < 3; ++a) {
+            for (int off = 32; off > 0; off >>= 1) { cmn[a] = fminf(cmn[a], __shfl_xor(cmn[a], off, 64)); cmx[a] = fmaxf(cmx[a], __shfl_xor(cmx[a], off, 64)); }
+            ext[a] = cmx[a] - cmn[a];
+            scale[a] = ext[a] > 0.f ? (float)B / ext[a] : 0.f;
+        }
+        auto bin_of = [&](const Box& b, int a) { const float c = 0.5f * (b.mn[a] + b.mx[a]); const int x = (int)((c - cmn[a]) * scale[a]); return x < 0 ? 0 : (x > B - 1 ? B - 1 : x); };
+        // ---- bins
+        wave_sync();   // (the previous range's readers are done)
+        for (int i = lane; i < 3 * B * 6; i += 64) (&wb.bb[0][0][0])[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+        for (int i = lane; i < 3 * B; i += 64) (&wb.num[0][0])[i] = 0u;
+        wave_sync();
+        for (int i = it.lo + lane; i <= it.hi; i += 64) {
+            const Box b = tri_box(tris[prim_in[i]]);
+            for (int a = 0; a < 3; ++a) {
+                if (!(ext[a] > 0.f)) continue;
+                const int x = bin_of(b, a);
+                for (int d = 0; d < 3; ++d) { atomicMin(&wb.bb[a][x][d], float_to_ordered(b.mn[d])); atomicMax(&wb.bb[a][x][3 + d], float_to_ordered(b.mx[d])); }
+                atomicAdd(&wb.num[a][x], 1u);
+            }
+        }
+        wave_sync();
+        // ---- 45 lanes, 45 planes: lane = axis * 15 + bin, the plane after that bin
+        float cost = FLT_MAX;
+        int my_nl = 0;
+        if (lane < 3 * (B - 1)) {
+            const int a = lane / (B - 1), pb = lane % (B - 1);
+            if (ext[a] > 0.f) {
+                Box l, r;
+                for (int x = 0; x < 3; ++x) { l.mn[x] = r.mn[x] = FLT_MAX; l.mx[x] = r.mx[x] = -FLT_MAX; }
+                uint32_t nl = 0, nr = 0;
+                for (int b = 0; b < B; ++b) {
+                    const uint32_t nb = wb.num[a][b];
+                    if (!nb) continue;
+                    Box& t = b <= pb ? l : r;
+                    for (int x = 0; x < 3; ++x) { t.mn[x] = fminf(t.mn[x], ordered_to_float(wb.bb[a][b][x])); t.mx[x] = fmaxf(t.mx[x], ordered_to_float(wb.bb[a][b][3 + x])); }
+                    if (b <= pb) nl += nb; else nr += nb;
+                }
+                if (nl != 0u && nr != 0u) {
+                    const int need = levels_needed(nl) > levels_needed(nr) ? levels_needed(nl) : levels_needed(nr);
+                    if (it.depth + need <= depth_limit) { cost = half_area(l) * (float)nl + half_area(r) * (float)nr; my_nl = (int)nl; }
+                }
+            }
+        }
+        // first minimum in (axis, bin) order = lowest lane among the cheapest
+        float best = cost;
+        int best_lane = lane;
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oc = __shfl_xor(best, off, 64);
+            const int ol = __shfl_xor(best_lane, off, 64);
+            if (oc < best || (oc == best && ol < best_lane)) { best = oc; best_lane = ol; }
+        }
+        const bool planar = best < FLT_MAX;
+        const int axis = planar ? best_lane / (B - 1) : -1, pbin = planar ? best_lane % (B - 1) : 0;
+        const int nl = planar ? __shfl(my_nl, best_lane, 64) : m / 2;   // no plane (equal centres, or the depth guard): the median position
+        // ---- stable partition
+        int run_l = 0, run_r = 0;
+        for (int base = it.lo; base <= it.hi; base += 64) {
+            const int i = base + lane;
+            const bool in = i <= it.hi;
+            uint32_t t = 0;
+            bool left = false;
+            if (in) {
+                t = prim_in[i];
+                left = planar ? bin_of(tri_box(tris[t]), axis) <= pbin : (i - it.lo) < nl;
+            }
+            const unsigned long long ml = __ballot(in && left);
+            const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+            const int my_l = (int)__popcll(ml & below);
+            if (in) prim_out[left ? it.lo + run_l + my_l : it.lo + nl + run_r + (lane - my_l)] = t;
+            const int chunk = it.hi - base + 1 < 64 ? it.hi - base + 1 : 64;
+            run_l += (int)__popcll(ml);
+            run_r += chunk - (int)__popcll(ml);
+        }
+        // ---- the node, its sides
+        const int gamma = it.lo + nl - 1;
+        if (lane == 0) {
+            parent[gamma] = it.parent;
+            live[gamma] = 1u;
+            if ((uint32_t)it.depth > __hip_atomic_load(&stats->max_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats->max_depth, (uint32_t)it.depth);
+            if (it.parent >= 0) child[2 * it.parent + it.side] = gamma; else *root_out = gamma;
+        }
+        __threadfence();   // the partition and parent[gamma] are written before a lane of this wave reads them back as a leaf
+        if (lane < 2) {
+            const int lo = lane == 0 ? it.lo : gamma + 1, hi = lane == 0 ? gamma : it.hi;
+            if ((uint32_t)(hi - lo + 1) <= kLeafMax) {
+                make_leaf(lo, hi, gamma, lane, tris, prim_out, prim_final, parent, child, leaf_box, node_box, arrived);
+            } else {
+                const unsigned int pos = atomicAdd(next_count, 1u);
+                next_items[pos] = Item{lo, hi, gamma, lane, it.depth + 1};
+            }
+        }
     }
 }
 
@@ -352,93 +669,6 @@ __global__ __launch_bounds__(kBlock) void k_triangles(const Tri* __restrict__ tr
     r[11] = 0.f;
 }
 
-// ---- SAH top tree over the Morton clusters (host, one thread: <= 32768 clusters). The Morton curve clusters the upper
-// levels of a scene badly (a split at the highest differing bit is a spatial-median split, whatever the geometry), and that
-// is where a linear BVH loses against SAH; inside a small cluster the difference is nil. So the upper levels are
-// built with binned SAH (16 bins, cost = half area x triangle count) over the cluster boxes, and every cluster becomes a
-// seed range for the linear build below its leaf.
-struct TopNode { int parent, side, child[2], depth; };   // child: >= 0 top node, < 0: ~cluster
-struct Cluster { Box box; float c[3]; uint32_t lo, hi, count; };
-
-struct TopBuilder {
-    const std::vector<Cluster>& cl;
-    std::vector<int> order;
-    std::vector<TopNode> nodes;
-    int max_seed_depth;   // deepest record a cluster's root may be
-
-    static int ceil_log2(uint32_t k) { int l = 0; while ((1u << l) < k) ++l; return l; }
-
-    // builds the sub-tree over order[begin, end) whose root record sits at `depth`; returns its link
-    int build(int begin, int end, int depth, int parent, int side) {
-        const int k = end - begin;
-        if (k == 1) return ~order[(size_t)begin];
-        const int me = (int)nodes.size();
-        nodes.push_back(TopNode{parent, side, {0, 0}, depth});
-        // bounds of the centroids, bins
-        float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int i = begin; i < end; ++i)
-            for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], cl[(size_t)order[(size_t)i]].c[a]); cmx[a] = std::max(cmx[a], cl[(size_t)order[(size_t)i]].c[a]); }
-        constexpr int B = 16;
-        float best = FLT_MAX;
-        int best_axis = -1, best_bin = -1;
-        for (int a = 0; a < 3; ++a) {
-            const float ext = cmx[a] - cmn[a];
-            if (!(ext > 0.f)) continue;
-            Box bb[B];
-            uint32_t cnt[B] = {0}, num[B] = {0};
-            for (int b = 0; b < B; ++b) for (int x = 0; x < 3; ++x) { bb[b].mn[x] = FLT_MAX; bb[b].mx[x] = -FLT_MAX; }
-            const float scale = (float)B / ext;
-            for (int i = begin; i < end; ++i) {
-                const Cluster& c = cl[(size_t)order[(size_t)i]];
-                const int b = std::min(B - 1, std::max(0, (int)((c.c[a] - cmn[a]) * scale)));
-                for (int x = 0; x < 3; ++x) { bb[b].mn[x] = std::min(bb[b].mn[x], c.box.mn[x]); bb[b].mx[x] = std::max(bb[b].mx[x], c.box.mx[x]); }
-                cnt[b] += c.count;
-                num[b] += 1u;
-            }
-            float rarea[B];
-            uint32_t rcnt[B], rnum[B];
-            Box acc;
-            for (int x = 0; x < 3; ++x) { acc.mn[x] = FLT_MAX; acc.mx[x] = -FLT_MAX; }
-            uint32_t c = 0, m = 0;
-            auto area = [](const Box& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return (dx < 0.f || dy < 0.f || dz < 0.f) ? 0.f : dx * dy + dy * dz + dz * dx; };
-            for (int b = B - 1; b > 0; --b) {
-                for (int x = 0; x < 3; ++x) { acc.mn[x] = std::min(acc.mn[x], bb[b].mn[x]); acc.mx[x] = std::max(acc.mx[x], bb[b].mx[x]); }
-                c += cnt[b]; m += num[b];
-                rarea[b] = area(acc); rcnt[b] = c; rnum[b] = m;
-            }
-            Box lacc;
-            for (int x = 0; x < 3; ++x) { lacc.mn[x] = FLT_MAX; lacc.mx[x] = -FLT_MAX; }
-            uint32_t lc = 0, lm = 0;
-            for (int b = 0; b < B - 1; ++b) {
-                for (int x = 0; x < 3; ++x) { lacc.mn[x] = std::min(lacc.mn[x], bb[b].mn[x]); lacc.mx[x] = std::max(lacc.mx[x], bb[b].mx[x]); }
-                lc += cnt[b]; lm += num[b];
-                if (lm == 0 || rnum[b + 1] == 0) continue;
-                // depth guard: both sides must still fit below max_seed_depth
-                if (depth + 1 + ceil_log2(std::max(lm, rnum[b + 1])) > max_seed_depth) continue;
-                const float cost = area(lacc) * (float)lc + rarea[b + 1] * (float)rcnt[b + 1];
-                if (cost < best) { best = cost; best_axis = a; best_bin = b; }
-            }
-        }
-        int mid = begin + k / 2;
-        if (best_axis >= 0) {
-            const float scale = (float)B / (cmx[best_axis] - cmn[best_axis]);
-            auto it = std::stable_partition(order.begin() + begin, order.begin() + end, [&](int ci) {
-                return std::min(B - 1, std::max(0, (int)((cl[(size_t)ci].c[best_axis] - cmn[best_axis]) * scale))) <= best_bin;
-            });
-            mid = (int)(it - order.begin());
-        } else {   // median by number of clusters along the widest axis (equal centroids, or the depth guard)
-            int axis = 0;
-            for (int a = 1; a < 3; ++a) if (cmx[a] - cmn[a] > cmx[axis] - cmn[axis]) axis = a;
-            std::stable_sort(order.begin() + begin, order.begin() + end, [&](int x, int y) { return cl[(size_t)x].c[axis] < cl[(size_t)y].c[axis]; });
-        }
-        const int c0 = build(begin, mid, depth + 1, me, 0);
-        const int c1 = build(mid, end, depth + 1, me, 1);
-        nodes[(size_t)me].child[0] = c0;
-        nodes[(size_t)me].child[1] = c1;
-        return me;
-    }
-};
-
 // One arena for every temporary (a hipMalloc costs more than most of these kernels), freed on every return path;
 // the arrays that outlive the build are separate allocations.
 struct Scratch {
@@ -490,7 +720,7 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     size_t scan_bytes_n = 0;
     LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes_n, (uint32_t*)nullptr, (uint32_t*)nullptr, ni, stream));
     // triangles 40, keys 2 x 8, values 4, parent 4, child links 8, boxes 2 x 24, counters 3 x 4, work queues 2 x 16 bytes per triangle
-    LB_TRY(tmp.reserve(n * 224 + sort_bytes + scan_bytes + scan_bytes_n + (2u << 20)));
+    LB_TRY(tmp.reserve(n * 320 + sort_bytes + scan_bytes + scan_bytes_n + (5u << 20)));
     Tri* d_tris = nullptr;
     LB_TRY(tmp.alloc(&d_tris, n));
     LB_TRY(hipMemcpyAsync(d_tris, tris.data(), n * sizeof(Tri), hipMemcpyHostToDevice, stream));
@@ -568,18 +798,28 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     int depth_limit = std::min(bvh::kMaxDepth, std::max(kDepthAim, levels_needed((uint32_t)n) + 10));
     if (const char* e = getenv("TRH_LBVH_DEPTH")) depth_limit = std::max(levels_needed((uint32_t)n) + 1, std::min(bvh::kMaxDepth, atoi(e)));
 
+    // (statistics and the per-generation queue lengths: the device-side top tree already writes to both)
+    Stats* d_stats = nullptr;
+    LB_TRY(tmp.alloc(&d_stats, 1));
+    LB_TRY(hipMemsetAsync(d_stats, 0, sizeof(Stats), stream));
+    unsigned int* d_counts = nullptr;
+    LB_TRY(tmp.alloc(&d_counts, (size_t)bvh::kMaxDepth + 3));
+    LB_TRY(hipMemsetAsync(d_counts, 0, ((size_t)bvh::kMaxDepth + 3) * sizeof(unsigned int), stream));
     // ---- seeds: the whole range under no parent (plain linear BVH), or one range per Morton cluster under an SAH top tree
     size_t n_seeds = 1;
-    uint32_t top_depth = 0;
     bool seeded = false;
     const char* top_env = getenv("TRH_LBVH_TOP");   // development override: 0 = plain linear BVH
     if (!(top_env && atoi(top_env) == 0) && n >= 4096) {
-        // cluster = shared top `bits` Morton bits (a cube of the centroid grid), about 8 triangles each where 2^15 cubes
-        // allow it (dragon 100 k: 32 per cluster 12.4 ms per 64 spp, 8 per cluster 11.9; more cubes cost host time)
+        // cluster = shared top `bits` Morton bits (a cube of the centroid grid). Round 2 (top tree by one host thread): about 8
+        // triangles each, at most 2^15 cubes. With the top tree on the device the cubes can be as fine as two triangles each
+        // (at most 2^21 cubes): the top tree is then nearly the whole tree, i.e. binned SAH over boxes of triangle pairs --
+        // dragon 8.93 -> 8.64 ms per 64 spp (host SAH tree: 8.39), SAH cost 11.6 -> 10.5 (10.3), profiles/r03_lbvh.txt
         int bits = 6;
-        size_t per_cluster = 8;
+        size_t per_cluster = 2;
         if (const char* e = getenv("TRH_LBVH_CLUSTER")) per_cluster = (size_t)std::max(1, atoi(e));   // development knob
-        while (bits < 15 && ((size_t)1 << bits) * per_cluster < n) bits += 3;
+        int max_bits = 21;
+        if (const char* e = getenv("TRH_LBVH_MAXBITS")) max_bits = std::min(24, std::max(6, atoi(e)));   // development knob
+        while (bits < max_bits && ((size_t)1 << bits) * per_cluster < n) bits += 3;
         uint32_t *d_flags = nullptr, *d_cidx = nullptr, *d_starts = nullptr;
         unsigned char* d_scan2 = nullptr;
         Box* d_cboxes = nullptr;
@@ -589,110 +829,92 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
         hipLaunchKernelGGL(k_cluster_flags, dim3(grid_n), dim3(kBlock), 0, stream, d_keys_sorted, (uint32_t)n, 63 - bits, d_flags);
         LB_TRY(hipGetLastError());
         LB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan2, scan_bytes_n, d_flags, d_cidx, ni, stream));
-        uint32_t last_flag = 0, last_cidx = 0;
+        // cluster starts and boxes for the upper bound of their number, then the one small read-back of the seeding (12 bytes):
+        // how many clusters there are and how big the biggest is decide the launch sizes and the depth budget below
+        const size_t cluster_cap = std::min<size_t>(n, (size_t)1 << bits);
+        uint32_t* d_biggest = nullptr;
+        LB_TRY(tmp.alloc(&d_starts, cluster_cap));
+        LB_TRY(tmp.alloc(&d_cboxes, cluster_cap));
+        LB_TRY(tmp.alloc(&d_biggest, 1));
+        LB_TRY(hipMemsetAsync(d_biggest, 0, 4, stream));
+        hipLaunchKernelGGL(k_cluster_starts, dim3(grid_n), dim3(kBlock), 0, stream, d_flags, d_cidx, (uint32_t)n, d_starts);
+        LB_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_cluster_boxes, dim3((unsigned)((cluster_cap + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_tris, d_prim, d_starts, d_flags, d_cidx, (uint32_t)n, d_cboxes, d_biggest);
+        LB_TRY(hipGetLastError());
+        uint32_t last_flag = 0, last_cidx = 0, biggest = 0;
         LB_TRY(hipMemcpyAsync(&last_flag, d_flags + (n - 1), 4, hipMemcpyDeviceToHost, stream));
         LB_TRY(hipMemcpyAsync(&last_cidx, d_cidx + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        LB_TRY(hipMemcpyAsync(&biggest, d_biggest, 4, hipMemcpyDeviceToHost, stream));
         LB_TRY(hipStreamSynchronize(stream));
         const uint32_t n_clusters = last_cidx + last_flag;
-        if (n_clusters >= 2 && n_clusters <= (1u << 15)) {
-            LB_TRY(tmp.alloc(&d_starts, n_clusters));
-            LB_TRY(tmp.alloc(&d_cboxes, n_clusters));
-            hipLaunchKernelGGL(k_cluster_starts, dim3(grid_n), dim3(kBlock), 0, stream, d_flags, d_cidx, (uint32_t)n, d_starts);
-            LB_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_cluster_boxes, dim3((n_clusters + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_tris, d_prim, d_starts, n_clusters, (uint32_t)n, d_cboxes);
-            LB_TRY(hipGetLastError());
-            std::vector<uint32_t> starts(n_clusters);
-            std::vector<Box> cboxes(n_clusters);
-            LB_TRY(hipMemcpyAsync(starts.data(), d_starts, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, stream));
-            LB_TRY(hipMemcpyAsync(cboxes.data(), d_cboxes, (size_t)n_clusters * sizeof(Box), hipMemcpyDeviceToHost, stream));
-            LB_TRY(hipStreamSynchronize(stream));
-            std::vector<Cluster> cl(n_clusters);
-            uint32_t biggest = 0;
-            for (uint32_t c = 0; c < n_clusters; ++c) {
-                cl[c].box = cboxes[c];
-                cl[c].lo = starts[c];
-                cl[c].hi = (c + 1 < n_clusters ? starts[c + 1] : (uint32_t)n) - 1u;
-                cl[c].count = cl[c].hi - cl[c].lo + 1u;
-                for (int a = 0; a < 3; ++a) cl[c].c[a] = 0.5f * (cboxes[c].mn[a] + cboxes[c].mx[a]);
-                biggest = std::max(biggest, cl[c].count);
-            }
+        if (n_clusters >= 2 && n_clusters <= cluster_cap) {
+            // ---- the top tree on the device (k_top_level): one launch per level, no data to the host and back
             // a cluster's root record at depth D needs D + levels_needed(count) <= depth_limit to be finishable by medians
             const int max_seed_depth = depth_limit - levels_needed(biggest);
-            if (1 + TopBuilder::ceil_log2(n_clusters) <= max_seed_depth) {
-                TopBuilder tb{cl, {}, {}, max_seed_depth};
-                tb.order.resize(n_clusters);
-                for (uint32_t c = 0; c < n_clusters; ++c) tb.order[c] = (int)c;
-                tb.nodes.reserve(n_clusters);
-                const int root_link = tb.build(0, (int)n_clusters, 1, -1, 0);
-                // a top node takes the last sorted position of a cluster as its index: the linear build below uses the
-                // positions [lo, hi - 1] of a range for its own nodes, so these are free (n_clusters - 1 nodes, and the
-                // last cluster's last position, n - 1, is outside the node arrays and stays unused)
-                auto node_id = [&](int t) { return (int)cl[(size_t)t].hi; };
-                std::vector<Item> seeds(n_clusters);
-                std::vector<int> h_parent(tb.nodes.size()), h_ids(tb.nodes.size());
-                std::vector<int> h_child(tb.nodes.size() * 2);
-                size_t ns = 0;
-                for (size_t t = 0; t < tb.nodes.size(); ++t) {
-                    const TopNode& tn = tb.nodes[t];
-                    h_ids[t] = node_id((int)t);
-                    h_parent[t] = tn.parent >= 0 ? node_id(tn.parent) : -1;
-                    top_depth = std::max(top_depth, (uint32_t)tn.depth);
-                    for (int sd = 0; sd < 2; ++sd) {
-                        const int link = tn.child[sd];
-                        if (link >= 0) h_child[2 * t + sd] = node_id(link);
-                        else {
-                            const Cluster& c = cl[(size_t)~link];
-                            h_child[2 * t + sd] = kLinkUnknown;   // written by the range's own thread (inner node or leaf)
-                            seeds[ns++] = Item{(int)c.lo, (int)c.hi, node_id((int)t), sd, tn.depth + 1};
-                        }
-                    }
-                }
-                if (root_link >= 0 && ns == n_clusters) {
-                    // scatter the top nodes into the node arrays (a few thousand words: one small kernel-free path via
-                    // per-array staging would need index lists; the arrays are written entry by entry from pinned-less
-                    // host memory in three strided copies instead)
-                    int *d_ids = nullptr, *d_hp = nullptr, *d_hc = nullptr;
-                    LB_TRY(tmp.alloc(&d_ids, tb.nodes.size()));
-                    LB_TRY(tmp.alloc(&d_hp, tb.nodes.size()));
-                    LB_TRY(tmp.alloc(&d_hc, tb.nodes.size() * 2));
-                    LB_TRY(hipMemcpyAsync(d_ids, h_ids.data(), h_ids.size() * 4, hipMemcpyHostToDevice, stream));
-                    LB_TRY(hipMemcpyAsync(d_hp, h_parent.data(), h_parent.size() * 4, hipMemcpyHostToDevice, stream));
-                    LB_TRY(hipMemcpyAsync(d_hc, h_child.data(), h_child.size() * 4, hipMemcpyHostToDevice, stream));
-                    hipLaunchKernelGGL(k_scatter_top, dim3((unsigned)((tb.nodes.size() + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_ids, d_hp, d_hc, (int)tb.nodes.size(),
-                                       d_parent, d_child, d_live);
+            int clog = 0;
+            while ((1u << clog) < n_clusters) ++clog;
+            if (biggest >= 1 && 1 + clog <= max_seed_depth) {
+                TopItem *d_top_a = nullptr, *d_top_b = nullptr;
+                int *d_order_a = nullptr, *d_order_b = nullptr;
+                unsigned int* d_top_counts = nullptr;   // [level]: items of the level; level 1 = the root
+                LB_TRY(tmp.alloc(&d_top_a, n_clusters));
+                LB_TRY(tmp.alloc(&d_top_b, n_clusters));
+                LB_TRY(tmp.alloc(&d_order_a, n_clusters));
+                LB_TRY(tmp.alloc(&d_order_b, n_clusters));
+                LB_TRY(tmp.alloc(&d_top_counts, (size_t)bvh::kMaxDepth + 3));
+                LB_TRY(hipMemsetAsync(d_top_counts, 0, ((size_t)bvh::kMaxDepth + 3) * sizeof(unsigned int), stream));
+                const TopItem root_top{0, (int)n_clusters, -1, 0, 1};
+                const unsigned int one = 1u;
+                LB_TRY(hipMemcpyAsync(d_top_a, &root_top, sizeof(root_top), hipMemcpyHostToDevice, stream));
+                LB_TRY(hipMemcpyAsync(d_top_counts + 1, &one, sizeof(one), hipMemcpyHostToDevice, stream));
+                hipLaunchKernelGGL(k_iota, dim3((n_clusters + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_order_a, (int)n_clusters);
+                LB_TRY(hipGetLastError());
+                for (int level = 1; level < max_seed_depth; ++level) {
+                    // nodes of a level: at most 2^(level-1), at most one per two clusters
+                    const size_t bound = std::min<size_t>(level > 20 ? n_clusters : ((size_t)1 << (level - 1)), (size_t)n_clusters / 2 + 1);
+                    hipLaunchKernelGGL(k_top_level, dim3((unsigned)bound), dim3(kBlock), 0, stream, d_top_a, d_top_counts + level, d_top_b, d_top_counts + level + 1, d_order_a, d_order_b,
+                                       d_cboxes, d_starts, n_clusters, (uint32_t)n, max_seed_depth, d_items_a, d_counts + 1, d_stats, d_parent, d_child, d_live, d_root);
                     LB_TRY(hipGetLastError());
-                    const int root_id = node_id(root_link);
-                    LB_TRY(hipMemcpyAsync(d_root, &root_id, 4, hipMemcpyHostToDevice, stream));
-                    LB_TRY(hipMemcpyAsync(d_items_a, seeds.data(), ns * sizeof(Item), hipMemcpyHostToDevice, stream));
-                    LB_TRY(hipStreamSynchronize(stream));   // the host vectors above go out of scope
-                    n_seeds = ns;
-                    seeded = true;
+                    std::swap(d_top_a, d_top_b);
+                    std::swap(d_order_a, d_order_b);
                 }
+                n_seeds = n_clusters;   // every cluster ends as a seed (the guard leaves room for the medians that get it there)
+                seeded = true;
             }
         }
     }
     if (!seeded) {
         const Item root_item{0, ni - 1, -1, 0, 1};
         LB_TRY(hipMemcpyAsync(d_items_a, &root_item, sizeof(Item), hipMemcpyHostToDevice, stream));
-        top_depth = 0;
     }
     // Every level is launched with an upper bound of its queue length (2^(depth-1), at most n ranges) and reads the
     // real length from the device: no host round trip per level. The depth guard ends the tree at kMaxDepth records;
     // level kMaxDepth + 1 only holds leaves.
-    Stats* d_stats = nullptr;
-    LB_TRY(tmp.alloc(&d_stats, 1));
-    LB_TRY(hipMemsetAsync(d_stats, 0, sizeof(Stats), stream));
-    unsigned int* d_counts = nullptr;
-    LB_TRY(tmp.alloc(&d_counts, (size_t)bvh::kMaxDepth + 3));
-    LB_TRY(hipMemsetAsync(d_counts, 0, ((size_t)bvh::kMaxDepth + 3) * sizeof(unsigned int), stream));
     const unsigned int first_count = (unsigned int)n_seeds;
     LB_TRY(hipMemcpyAsync(d_counts + 1, &first_count, sizeof(first_count), hipMemcpyHostToDevice, stream));
-    if (top_depth) LB_TRY(hipMemcpyAsync(&d_stats->max_depth, &top_depth, sizeof(top_depth), hipMemcpyHostToDevice, stream));
+    const char* split_env = getenv("TRH_LBVH_SPLIT");   // development override: "morton" = the linear BVH's splits (k_level) below the top tree
+    const bool sah_splits = !(split_env && std::string(split_env) == "morton");
+    uint32_t *d_prim_a = nullptr, *d_prim_b = nullptr;
+    if (sah_splits) {
+        LB_TRY(tmp.alloc(&d_prim_a, n));
+        LB_TRY(tmp.alloc(&d_prim_b, n));
+    }
+    const uint32_t* prim_in = d_prim;   // generation 1 reads the Morton order; a leaf writes its final order back into d_prim
+    uint32_t* prim_out = d_prim_a;
     for (int depth = 1; depth <= bvh::kMaxDepth + 1; ++depth) {
         // (generation `depth` of the work queue: with seeds the records of one generation sit at different tree depths)
         const size_t bound = depth > 27 ? n : std::min<size_t>(n, n_seeds << (depth - 1));
-        hipLaunchKernelGGL(k_level, dim3((unsigned)((bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_items_a, (int)bound, depth_limit, d_keys_sorted, d_tris, d_prim,
-                           d_items_b, d_counts + depth, d_counts + depth + 1, d_stats, d_parent, d_child, d_live, d_leaf_box, d_node_box, d_arrived, d_root);
+        if (sah_splits) {
+            // one wave per range, waves stride over the queue (its real length is read on the device)
+            const size_t blocks = std::min<size_t>((bound + (kBlock / 64) - 1) / (kBlock / 64), 4096);
+            hipLaunchKernelGGL(k_level_sah, dim3((unsigned)blocks), dim3(kBlock), 0, stream, d_items_a, d_counts + depth, d_items_b, d_counts + depth + 1, depth_limit, d_tris, prim_in,
+                               prim_out, d_prim, d_stats, d_parent, d_child, d_live, d_leaf_box, d_node_box, d_arrived, d_root);
+            prim_in = prim_out;
+            prim_out = prim_out == d_prim_a ? d_prim_b : d_prim_a;
+        } else {
+            hipLaunchKernelGGL(k_level, dim3((unsigned)((bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_items_a, (int)bound, depth_limit, d_keys_sorted, d_tris, d_prim,
+                               d_items_b, d_counts + depth, d_counts + depth + 1, d_stats, d_parent, d_child, d_live, d_leaf_box, d_node_box, d_arrived, d_root);
+        }
         LB_TRY(hipGetLastError());
         std::swap(d_items_a, d_items_b);
     }

@@ -1245,6 +1245,7 @@ int trh_init(int device, trh_context** ctx_out) {
         const int v = atoi(e);
         if (v >= 8 && v <= 26) c->wf_pool_limit = 1u << v;
     }
+    if (const char* e = getenv("TRH_BUILDER")) { if (std::string(e) == "lbvh") c->builder = TRH_BUILDER_DEVICE_LBVH; }   // default of new contexts
     if (const char* e = getenv("TRH_LDS_PAD")) c->lds_pad = (size_t)atoi(e);
     if (const char* e = getenv("TRH_STATS_AB")) c->stats_ab = atoi(e) != 0;
     if (const char* e = getenv("TRH_CAMERA_PACKETS")) c->camera_packets = atoi(e) != 0;   // development knob: 0 = k_megakernel for every launch
