@@ -3,16 +3,18 @@
 // The reference builds its kd-tree on the host at start-up (kdtree.h:160-354, seconds on the dragon)
 // and its CUDA module has no acceleration structure at all (cuda_trace.cu:22-46). The default builder
 // of this module is the host-side binned-SAH build (bvh_builder.h); this is the alternative for
-// scenes whose start-up time matters more than traversal speed (1.6 M triangles in 30 ms instead of
-// 320 ms; the render is 5-17 % slower): a linear BVH built on the GPU -- 63-bit Morton codes of the
-// triangle centroids, one radix sort, a top-down pass per tree level that splits every range where
-// its highest differing code bit flips (with the host builder's depth guard), a bottom-up box fit,
-// ranges of <= 2 triangles as leaves, records compacted and emitted directly in the two formats the
-// kernels traverse (bvh_builder.h). Round 2: the UPPER levels, where the Morton order clusters badly,
-// are built with binned SAH over the boxes of <= 32768 Morton clusters (a few hundred KB to the host
-// and back, a few ms on one host thread): 45 -> 34 box tests per ray on the dragon. The arrays stay in
-// HBM; only the leaf-order -> input-triangle permutation goes back to the host (it orders the
-// shading records).
+// scenes whose start-up time matters (1.6 M triangles in 63 ms instead of 350 ms, the dragon in 12
+// instead of 25; the render is 2-6 % slower), built entirely on the GPU: 63-bit Morton codes of the
+// triangle centroids and one radix sort group the triangles into Morton clusters of about two; the
+// UPPER levels are binned SAH over the cluster boxes (a launch per level, a workgroup per node); below
+// a cluster the ranges are split by binned SAH as well (a launch per generation, a wave per range),
+// with the host builder's depth guard; a bottom-up box fit, ranges of <= 2 triangles as leaves,
+// records compacted and emitted directly in the two formats the kernels traverse (bvh_builder.h).
+// History: round 1 was a plain linear BVH (splits at the highest differing Morton bit: 28-33 % slower
+// to render than the SAH tree), round 2 put an SAH top tree over <= 32768 clusters, built by one host
+// thread (15-18 %), round 3 moved it to the device, shrank the clusters and replaced the Morton splits.
+// The arrays stay in HBM; only the leaf-order -> input-triangle permutation goes back to the host (it
+// orders the shading records).
 #pragma once
 #include <hip/hip_runtime.h>
 
