@@ -3,12 +3,13 @@
 // The reference builds its kd-tree on the host at start-up (kdtree.h:160-354, seconds on the dragon)
 // and its CUDA module has no acceleration structure at all (cuda_trace.cu:22-46). The default builder
 // of this module is the host-side binned-SAH build (bvh_builder.h); this is the alternative for
-// scenes whose start-up time matters (1.6 M triangles in 63 ms instead of 350 ms, the dragon in 12
-// instead of 25; the render is 2-6 % slower), built entirely on the GPU: 63-bit Morton codes of the
+// scenes whose start-up time matters (1.6 M triangles in 22 ms instead of 350 ms, the dragon in 10
+// instead of 25; the render is 2-5 % slower), built entirely on the GPU: 63-bit Morton codes of the
 // triangle centroids and one radix sort group the triangles into Morton clusters of about two; the
 // UPPER levels are binned SAH over the cluster boxes (a launch per level, a workgroup per node); below
 // a cluster the ranges are split by binned SAH as well (a launch per generation, a wave per range),
-// with the host builder's depth guard; a bottom-up box fit, ranges of <= 2 triangles as leaves,
+// with the host builder's depth guard; ranges of <= 2 triangles are leaves, made by one launch at the
+// end (a thread per leaf: box, link, bottom-up box fit);
 // records compacted and emitted directly in the two formats the kernels traverse (bvh_builder.h).
 // History: round 1 was a plain linear BVH (splits at the highest differing Morton bit: 28-33 % slower
 // to render than the SAH tree), round 2 put an SAH top tree over <= 32768 clusters, built by one host

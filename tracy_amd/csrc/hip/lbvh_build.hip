@@ -407,8 +407,8 @@ __global__ __launch_bounds__(kBlock) void k_level(const Item* __restrict__ items
 // ordered integers), 45 lanes evaluate the 45 planes, stable partition by ballot + prefix count from `prim_in` into
 // `prim_out` (the arrays alternate between generations; a leaf copies its triangles to `prim_final`, the order the triangle
 // records are emitted in). Node index = split position, as in k_level: unique, so the layout does not depend on the order
-// of the work queue. Sides of <= kLeafMax triangles become leaves at once (box, link, bottom-up merge), larger ones are
-// queued for the next generation.
+// of the work queue. Sides of <= kLeafMax triangles go to the leaf queue (k_leaves, after the last generation), larger ones
+// to the next generation's.
 struct WaveBins { uint32_t bb[3][16][6]; uint32_t num[3][16]; };
 
 __device__ inline void wave_sync() {
@@ -416,24 +416,26 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// a leaf over the sorted positions [lo, hi] (one lane): final order, box, link, then up the tree as far as this lane is the second to arrive
-__device__ inline void make_leaf(int lo, int hi, int par, int side, const Tri* __restrict__ tris, const uint32_t* prim_src, uint32_t* prim_final,
-                                 int* parent, int* child, Box* leaf_box, Box* node_box, unsigned int* arrived) {
-    Box b;
-    for (int p = lo; p <= hi; ++p) {
-        const uint32_t t = prim_src[p];
-        prim_final[p] = t;
-        const Box tb = tri_box(tris[t]);
-        for (int a = 0; a < 3; ++a) {
-            b.mn[a] = p == lo ? tb.mn[a] : fminf(b.mn[a], tb.mn[a]);
-            b.mx[a] = p == lo ? tb.mx[a] : fmaxf(b.mx[a], tb.mx[a]);
-        }
+// the leaves of k_level_sah, one thread each, after the last generation (every parent link exists by then): box of the leaf's
+// triangles, leaf link, then up the tree as far as this thread is the second to arrive at a node (the classic bottom-up fit).
+// One launch for all leaves: the acquire / release pair per node costs an L2 write-back and invalidate on this chip, and
+// a thread per leaf shares them between the 64 leaves of a wave (made by a lane or two of the wave that had split their parent,
+// the leaves cost k_level_sah 48 ms for 1.6 M triangles; k_level_sah now takes 4.9 ms and this kernel 4.1: profiles/r03_lbvh.txt).
+__global__ __launch_bounds__(kBlock) void k_leaves(const Item* __restrict__ leaves, const unsigned int* __restrict__ leaf_count, const Tri* __restrict__ tris,
+                                                   const uint32_t* __restrict__ prim, const int* __restrict__ parent, int* child, Box* leaf_box, Box* node_box, unsigned int* arrived) {
+    const unsigned int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= *leaf_count) return;
+    const Item it = leaves[k];
+    Box b = tri_box(tris[prim[it.lo]]);
+    for (int p = it.lo + 1; p <= it.hi; ++p) {
+        const Box t = tri_box(tris[prim[p]]);
+        for (int a = 0; a < 3; ++a) { b.mn[a] = fminf(b.mn[a], t.mn[a]); b.mx[a] = fmaxf(b.mx[a], t.mx[a]); }
     }
-    leaf_box[lo] = b;
-    child[2 * par + side] = ~(int)(((uint32_t)lo << 4) | (uint32_t)(hi - lo + 1));
-    int node = par;
+    leaf_box[it.lo] = b;
+    child[2 * it.parent + it.side] = ~(int)(((uint32_t)it.lo << 4) | (uint32_t)(it.hi - it.lo + 1));
+    int node = it.parent;
     while (node >= 0) {
-        // release this lane's box and link, acquire the sibling's: the second to arrive carries on
+        // release this thread's box and link, acquire the sibling's: the second thread to arrive carries on
         const unsigned int old = __hip_atomic_fetch_add(&arrived[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (old == 0u) return;
         Box u;
@@ -451,20 +453,33 @@ __device__ inline void make_leaf(int lo, int hi, int par, int side, const Tri* _
 }
 
 __global__ __launch_bounds__(kBlock) void k_level_sah(const Item* __restrict__ items, const unsigned int* __restrict__ item_count, Item* __restrict__ next_items,
-                                                      unsigned int* __restrict__ next_count, int depth_limit, const Tri* __restrict__ tris, const uint32_t* prim_in,
-                                                      uint32_t* prim_out, uint32_t* prim_final, Stats* __restrict__ stats, int* parent, int* child,
-                                                      uint32_t* __restrict__ live, Box* leaf_box, Box* node_box, unsigned int* arrived, int* __restrict__ root_out) {
+                                                      unsigned int* __restrict__ next_count, Item* __restrict__ leaf_items, unsigned int* __restrict__ leaf_count, int depth_limit,
+                                                      const Tri* __restrict__ tris, const uint32_t* prim_in, uint32_t* prim_out, uint32_t* prim_final, Stats* __restrict__ stats,
+                                                      int* __restrict__ parent, int* __restrict__ child, uint32_t* __restrict__ live, int* __restrict__ root_out) {
     constexpr int B = 16;
     __shared__ WaveBins s_bins[kBlock / 64];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     WaveBins& wb = s_bins[wave];
     const unsigned int count = *item_count;
     const unsigned int total_waves = gridDim.x * (unsigned)(kBlock / 64);
+    // ranges for the next generation and leaves, gathered in the wave (lane j holds the j-th; everything about a range is
+    // wave-uniform) and appended to their queues with one atomic per ~60
+    Item buf = Item{0, 0, 0, 0, 0}, lbuf = buf;
+    int nbuf = 0, nlbuf = 0;   // wave-uniform
+    auto flush = [&](Item& b, int& nb, Item* out, unsigned int* out_count) {
+        if (nb == 0) return;
+        unsigned int pos = 0;
+        if (lane == 0) pos = atomicAdd(out_count, (unsigned int)nb);
+        pos = (unsigned int)__shfl((int)pos, 0, 64);
+        if (lane < nb) out[pos + (unsigned int)lane] = b;
+        nb = 0;
+    };
     for (unsigned int k = blockIdx.x * (unsigned)(kBlock / 64) + (unsigned)wave; k < count; k += total_waves) {
         const Item it = items[k];
         const int m = it.hi - it.lo + 1;
-        if ((uint32_t)m <= kLeafMax) {   // (a seed range as small as a leaf)
-            if (lane == 0) make_leaf(it.lo, it.hi, it.parent, it.side, tris, prim_in, prim_final, parent, child, leaf_box, node_box, arrived);
+        if ((uint32_t)m <= kLeafMax) {   // a seed range as small as a leaf (generation 1: prim_in is the final order already)
+            if (lane == nlbuf) lbuf = it;
+            if (++nlbuf >= 62) flush(lbuf, nlbuf, leaf_items, leaf_count);
             continue;
         }
         // ---- bounds of the centres
@@ -542,7 +557,11 @@ __global__ __launch_bounds__(kBlock) void k_level_sah(const Item* __restrict__ i
             const unsigned long long ml = __ballot(in && left);
             const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
             const int my_l = (int)__popcll(ml & below);
-            if (in) prim_out[left ? it.lo + run_l + my_l : it.lo + nl + run_r + (lane - my_l)] = t;
+            if (in) {
+                const int pos = left ? it.lo + run_l + my_l : it.lo + nl + run_r + (lane - my_l);
+                prim_out[pos] = t;
+                if ((uint32_t)(left ? nl : m - nl) <= kLeafMax) prim_final[pos] = t;   // a side that is a leaf: this is its final order
+            }
             const int chunk = it.hi - base + 1 < 64 ? it.hi - base + 1 : 64;
             run_l += (int)__popcll(ml);
             run_r += chunk - (int)__popcll(ml);
@@ -555,17 +574,16 @@ __global__ __launch_bounds__(kBlock) void k_level_sah(const Item* __restrict__ i
             if ((uint32_t)it.depth > __hip_atomic_load(&stats->max_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats->max_depth, (uint32_t)it.depth);
             if (it.parent >= 0) child[2 * it.parent + it.side] = gamma; else *root_out = gamma;
         }
-        __threadfence();   // the partition and parent[gamma] are written before a lane of this wave reads them back as a leaf
-        if (lane < 2) {
-            const int lo = lane == 0 ? it.lo : gamma + 1, hi = lane == 0 ? gamma : it.hi;
-            if ((uint32_t)(hi - lo + 1) <= kLeafMax) {
-                make_leaf(lo, hi, gamma, lane, tris, prim_out, prim_final, parent, child, leaf_box, node_box, arrived);
-            } else {
-                const unsigned int pos = atomicAdd(next_count, 1u);
-                next_items[pos] = Item{lo, hi, gamma, lane, it.depth + 1};
-            }
-        }
+        // the sides: leaves to the leaf queue (k_leaves), the others to the next generation
+        if ((uint32_t)nl > kLeafMax) { if (lane == nbuf) buf = Item{it.lo, gamma, gamma, 0, it.depth + 1}; ++nbuf; }
+        else { if (lane == nlbuf) lbuf = Item{it.lo, gamma, gamma, 0, it.depth + 1}; ++nlbuf; }
+        if ((uint32_t)(m - nl) > kLeafMax) { if (lane == nbuf) buf = Item{gamma + 1, it.hi, gamma, 1, it.depth + 1}; ++nbuf; }
+        else { if (lane == nlbuf) lbuf = Item{gamma + 1, it.hi, gamma, 1, it.depth + 1}; ++nlbuf; }
+        if (nbuf >= 62) flush(buf, nbuf, next_items, next_count);
+        if (nlbuf >= 62) flush(lbuf, nlbuf, leaf_items, leaf_count);
     }
+    flush(buf, nbuf, next_items, next_count);
+    flush(lbuf, nlbuf, leaf_items, leaf_count);
 }
 
 __device__ inline void pad_box(Box& b, float scene_extent) {   // == Builder::pad (bvh_builder.cpp)
@@ -720,7 +738,7 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     size_t scan_bytes_n = 0;
     LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes_n, (uint32_t*)nullptr, (uint32_t*)nullptr, ni, stream));
     // triangles 40, keys 2 x 8, values 4, parent 4, child links 8, boxes 2 x 24, counters 3 x 4, work queues 2 x 16 bytes per triangle
-    LB_TRY(tmp.reserve(n * 320 + sort_bytes + scan_bytes + scan_bytes_n + (5u << 20)));
+    LB_TRY(tmp.reserve(n * 344 + sort_bytes + scan_bytes + scan_bytes_n + (5u << 20)));
     Tri* d_tris = nullptr;
     LB_TRY(tmp.alloc(&d_tris, n));
     LB_TRY(hipMemcpyAsync(d_tris, tris.data(), n * sizeof(Tri), hipMemcpyHostToDevice, stream));
@@ -813,7 +831,7 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
         // cluster = shared top `bits` Morton bits (a cube of the centroid grid). Round 2 (top tree by one host thread): about 8
         // triangles each, at most 2^15 cubes. With the top tree on the device the cubes can be as fine as two triangles each
         // (at most 2^21 cubes): the top tree is then nearly the whole tree, i.e. binned SAH over boxes of triangle pairs --
-        // dragon 8.93 -> 8.64 ms per 64 spp (host SAH tree: 8.39), SAH cost 11.6 -> 10.5 (10.3), profiles/r03_lbvh.txt
+        // dragon 8.93 -> 8.64 ms per 64 spp (host SAH tree: 8.36), SAH cost 11.6 -> 10.5 (10.3), profiles/r03_lbvh.txt
         int bits = 6;
         size_t per_cluster = 2;
         if (const char* e = getenv("TRH_LBVH_CLUSTER")) per_cluster = (size_t)std::max(1, atoi(e));   // development knob
@@ -895,9 +913,11 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
     const char* split_env = getenv("TRH_LBVH_SPLIT");   // development override: "morton" = the linear BVH's splits (k_level) below the top tree
     const bool sah_splits = !(split_env && std::string(split_env) == "morton");
     uint32_t *d_prim_a = nullptr, *d_prim_b = nullptr;
+    Item* d_leaf_items = nullptr;   // every leaf of k_level_sah; its length is d_counts[0]
     if (sah_splits) {
         LB_TRY(tmp.alloc(&d_prim_a, n));
         LB_TRY(tmp.alloc(&d_prim_b, n));
+        LB_TRY(tmp.alloc(&d_leaf_items, n));
     }
     const uint32_t* prim_in = d_prim;   // generation 1 reads the Morton order; a leaf writes its final order back into d_prim
     uint32_t* prim_out = d_prim_a;
@@ -907,8 +927,8 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
         if (sah_splits) {
             // one wave per range, waves stride over the queue (its real length is read on the device)
             const size_t blocks = std::min<size_t>((bound + (kBlock / 64) - 1) / (kBlock / 64), 4096);
-            hipLaunchKernelGGL(k_level_sah, dim3((unsigned)blocks), dim3(kBlock), 0, stream, d_items_a, d_counts + depth, d_items_b, d_counts + depth + 1, depth_limit, d_tris, prim_in,
-                               prim_out, d_prim, d_stats, d_parent, d_child, d_live, d_leaf_box, d_node_box, d_arrived, d_root);
+            hipLaunchKernelGGL(k_level_sah, dim3((unsigned)blocks), dim3(kBlock), 0, stream, d_items_a, d_counts + depth, d_items_b, d_counts + depth + 1, d_leaf_items, d_counts, depth_limit,
+                               d_tris, prim_in, prim_out, d_prim, d_stats, d_parent, d_child, d_live, d_root);
             prim_in = prim_out;
             prim_out = prim_out == d_prim_a ? d_prim_b : d_prim_a;
         } else {
@@ -917,6 +937,10 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
         }
         LB_TRY(hipGetLastError());
         std::swap(d_items_a, d_items_b);
+    }
+    if (sah_splits) {
+        hipLaunchKernelGGL(k_leaves, dim3(grid_n), dim3(kBlock), 0, stream, d_leaf_items, d_counts, d_tris, d_prim, d_parent, d_child, d_leaf_box, d_node_box, d_arrived);
+        LB_TRY(hipGetLastError());
     }
     unsigned char* d_scan_tmp = nullptr;
     LB_TRY(tmp.alloc(&d_scan_tmp, scan_bytes));
