@@ -43,6 +43,12 @@ constexpr int kDepthAim = 27;             // see build(): the depth the guard ai
 #define TRH_LBVH_LEAF 2
 #endif
 constexpr uint32_t kLeafMax = TRH_LBVH_LEAF;
+// ... and with SAH splits (k_level_sah) a range of up to this many triangles stays a leaf when the host builder's rule says a leaf
+// is cheaper than its best split (n C_intersect <= C_traverse + C_intersect cost / area)
+#ifndef TRH_LBVH_SAH_LEAF
+#define TRH_LBVH_SAH_LEAF 4
+#endif
+constexpr uint32_t kSahLeafMax = TRH_LBVH_SAH_LEAF;
 // (C_traverse comes from the host builder at run time, bvh::cost_traverse(): one constant, one scale for trh_bvh_info.sah_cost)
 constexpr float kCostIntersect = 1.0f;
 
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void k_leaves(const Item* __restrict__ leav
 
 __global__ __launch_bounds__(kBlock) void k_level_sah(const Item* __restrict__ items, const unsigned int* __restrict__ item_count, Item* __restrict__ next_items,
                                                       unsigned int* __restrict__ next_count, Item* __restrict__ leaf_items, unsigned int* __restrict__ leaf_count, int depth_limit,
-                                                      const Tri* __restrict__ tris, const uint32_t* prim_in, uint32_t* prim_out, uint32_t* prim_final, Stats* __restrict__ stats,
+                                                      float cost_traverse, const Tri* __restrict__ tris, const uint32_t* prim_in, uint32_t* prim_out, uint32_t* prim_final, Stats* __restrict__ stats,
                                                       int* __restrict__ parent, int* __restrict__ child, uint32_t* __restrict__ live, int* __restrict__ root_out) {
     constexpr int B = 16;
     __shared__ WaveBins s_bins[kBlock / 64];
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_level_sah(const Item* __restrict__ i
         }
         wave_sync();
         // ---- 45 lanes, 45 planes: lane = axis * 15 + bin, the plane after that bin
-        float cost = FLT_MAX;
+        float cost = FLT_MAX, my_area = 0.f;
         int my_nl = 0;
         if (lane < 3 * (B - 1)) {
             const int a = lane / (B - 1), pb = lane % (B - 1);
@@ -528,7 +534,12 @@ __global__ __launch_bounds__(kBlock) void k_level_sah(const Item* __restrict__ i
                 }
                 if (nl != 0u && nr != 0u) {
                     const int need = levels_needed(nl) > levels_needed(nr) ? levels_needed(nl) : levels_needed(nr);
-                    if (it.depth + need <= depth_limit) { cost = half_area(l) * (float)nl + half_area(r) * (float)nr; my_nl = (int)nl; }
+                    if (it.depth + need <= depth_limit) {
+                        cost = half_area(l) * (float)nl + half_area(r) * (float)nr;
+                        my_nl = (int)nl;
+                        for (int x = 0; x < 3; ++x) { l.mn[x] = fminf(l.mn[x], r.mn[x]); l.mx[x] = fmaxf(l.mx[x], r.mx[x]); }
+                        my_area = half_area(l);   // the range's own box
+                    }
                 }
             }
         }
@@ -543,6 +554,16 @@ __global__ __launch_bounds__(kBlock) void k_level_sah(const Item* __restrict__ i
         const bool planar = best < FLT_MAX;
         const int axis = planar ? best_lane / (B - 1) : -1, pbin = planar ? best_lane % (B - 1) : 0;
         const int nl = planar ? __shfl(my_nl, best_lane, 64) : m / 2;   // no plane (equal centres, or the depth guard): the median position
+        // the host builder's leaf rule for small ranges
+        if ((uint32_t)m <= kSahLeafMax) {
+            const float area = planar ? __shfl(my_area, best_lane, 64) : 0.f;
+            if (!planar || kCostIntersect * (float)m <= cost_traverse + kCostIntersect * best / fmaxf(area, 1e-30f)) {
+                for (int i = it.lo + lane; i <= it.hi; i += 64) prim_final[i] = prim_in[i];
+                if (lane == nlbuf) lbuf = it;
+                if (++nlbuf >= 62) flush(lbuf, nlbuf, leaf_items, leaf_count);
+                continue;
+            }
+        }
         // ---- stable partition
         int run_l = 0, run_r = 0;
         for (int base = it.lo; base <= it.hi; base += 64) {
@@ -928,7 +949,7 @@ int build(const std::vector<bvh::InputTriangle>& tris, hipStream_t stream, Devic
             // one wave per range, waves stride over the queue (its real length is read on the device)
             const size_t blocks = std::min<size_t>((bound + (kBlock / 64) - 1) / (kBlock / 64), 4096);
             hipLaunchKernelGGL(k_level_sah, dim3((unsigned)blocks), dim3(kBlock), 0, stream, d_items_a, d_counts + depth, d_items_b, d_counts + depth + 1, d_leaf_items, d_counts, depth_limit,
-                               d_tris, prim_in, prim_out, d_prim, d_stats, d_parent, d_child, d_live, d_root);
+                               f.cost_traverse, d_tris, prim_in, prim_out, d_prim, d_stats, d_parent, d_child, d_live, d_root);
             prim_in = prim_out;
             prim_out = prim_out == d_prim_a ? d_prim_b : d_prim_a;
         } else {
