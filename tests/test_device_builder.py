@@ -93,6 +93,25 @@ def test_renders_like_the_host_built_tree(scene_loader, oracle_mod, name, w, h):
         b.Shutdown()
 
 
+def test_builder_default_from_the_environment(scene_loader, monkeypatch):
+    """TRH_BUILDER=lbvh makes the device build the default of new contexts (hosts that cannot call trh_set_builder)."""
+    from tracy_amd import HipTrace
+    monkeypatch.setenv("TRH_BUILDER", "lbvh")
+    mod = HipTrace()
+    mod.Startup(scene_loader("bunny", 64, 36))
+    try:
+        assert mod.bvh_info()["builder"] == 1
+    finally:
+        mod.Shutdown()
+    monkeypatch.delenv("TRH_BUILDER")
+    mod = HipTrace()
+    mod.Startup(scene_loader("bunny", 64, 36))
+    try:
+        assert mod.bvh_info()["builder"] == 0
+    finally:
+        mod.Shutdown()
+
+
 def test_tiny_scenes_use_the_host_builder(scene_loader):
     from tracy_amd import HipTrace, capi
     mod = HipTrace(builder=capi.TRH_BUILDER_DEVICE_LBVH)
